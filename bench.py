@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""
+bench.py -- graphs/sec of P+Q wavelet scattering, forward + backward, J=4
+(BASELINE.json metric), on synthetic ellipsoid batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (default = BASELINE.json configs[1], "cfg2"): per GPU a block-diagonal
+batch of 4096 graphs x 500 nodes, symmetrised kNN k=10, scalar track x = pos
+(C=3) on P (CSR), vector track x = pos on Q (BSR-3), dyadic J=4 + low-pass
+(T=16 products, F=6 filters).  One "step" = one pass of the hot path over that
+batch: P-chain fwd, Q-chain fwd, then both backward w.r.t. x for a fixed upstream
+gradient (what autograd of the reference's get_Batch_Wjxs does).  Operators are
+canonical (int32 CSR / BSR-3) and resident in HBM before the timed region.
+
+Multi-GPU: graphs are independent diagonal blocks, so ranks take disjoint
+batches of the same size and no collective is on the data path ("weak" scaling);
+value = graphs all ranks processed / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus
+  roofline      dominant kernel (Q-chain forward): algorithmic bytes per launch
+                (T(4(N+1)+40 nnz)+12N+12NF) / its mean HIP-event
+                duration inside the timed region, against 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle's torch.sparse.mm restatement of the reference
+                (kind "port"), timed on a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy)
+
+
+def alg_bytes_scalar(N, nnz, C, T, F):
+    return T * (4 * (N + 1) + 8 * nnz) + 4 * N * C + 4 * N * C * F
+
+
+def alg_bytes_vector(N, nnz, T, F):
+    return T * (4 * (N + 1) + 40 * nnz) + 12 * N + 12 * N * F
+
+
+def cpu_baseline(b, n_graphs, n_per_graph, J, threads):
+    """reference-equivalent CPU path (oracle/chain_oracle.ref_get_Batch_Wjxs: torch.sparse.mm on the
+    un-coalesced int64 COO operand, as models/escgnn_data_classes.py:137-142 builds it), fwd+bwd of both tracks."""
+    import numpy as np
+    import torch
+    from oracle import chain_oracle as co
+    N = n_graphs * n_per_graph
+    e1 = int(b["rowptr"][N])
+    rows = np.repeat(np.arange(N), np.diff(b["rowptr"][:N + 1])).astype(np.int64)
+    cols = b["col"][:e1].astype(np.int64)
+    P = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(b["pval"][:e1]), (N, N),
+                                dtype=torch.float32)
+    a = np.arange(3)
+    qr = (3 * rows)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]
+    qc = (3 * cols)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]
+    Q = torch.sparse_coo_tensor(torch.from_numpy(np.stack([qr.reshape(-1), qc.reshape(-1)])),
+                                torch.from_numpy(b["blk"][:e1].reshape(-1)), (3 * N, 3 * N), dtype=torch.float32)
+    torch.set_num_threads(threads)
+    xs = torch.from_numpy(b["pos"][:N]).clone().requires_grad_(True)
+    xv = torch.from_numpy(b["pos"][:N]).reshape(-1, 1).clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    Ws = co.ref_get_Batch_Wjxs(xs, P, scales_type="dyadic", J=J)
+    Wv = co.ref_get_Batch_Wjxs(xv, Q, scales_type="dyadic", J=J)
+    Ws.backward(torch.ones_like(Ws))
+    Wv.backward(torch.ones_like(Wv))
+    dt = time.perf_counter() - t0
+    return n_graphs / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU (cfg2: 4096)")
+    ap.add_argument("--nodes", type=int, default=500)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--J", type=int, default=4)
+    ap.add_argument("--cpu-sample-graphs", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # ---- inputs (host, before the GPU is touched: the generator forks workers)
+    from esc_gnn_amd import synthetic
+    workers = min(16, os.cpu_count() or 1)
+    b = synthetic.ellipsoid_batch(args.graphs, args.nodes, args.k, seed=457892 + 1 + rank, workers=workers)
+    N, nnz = b["N"], b["nnz"]
+
+    import torch
+    import torch.distributed as dist
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain, load_library
+    load_library()                      # raises if libescat.so is missing: no fallback
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rowptr, col = t(b["rowptr"]), t(b["col"])
+    opP = ScatterOperator.from_csr(rowptr, col, t(b["pval"]), N)
+    opQ = ScatterOperator.from_bsr3(rowptr, col, t(b["blk"]), N)
+    opP.csr_t(); opQ.bsr3_t()           # canonicalisation (transposes for the backward walk) outside the timed region
+    plan = plan_chain(scales_type="dyadic", J=args.J)
+    T, F, C = plan.T, plan.F, 3
+    xs = t(b["pos"]).clone().requires_grad_(True)
+    xv = t(b["pos"]).reshape(-1, 1).clone().requires_grad_(True)
+    gs = torch.randn(N, C, F, device=dev)
+    gv = torch.randn(3 * N, 1, F, device=dev)
+
+    names = ("P_fwd", "Q_fwd", "P_bwd", "Q_bwd")
+    evs = []
+
+    def step(record):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+        xs.grad = None; xv.grad = None
+        if record: e[0].record()
+        Ws = get_Batch_Wjxs(xs, opP, scales_type="dyadic", J=args.J)
+        if record: e[1].record()
+        Wv = get_Batch_Wjxs(xv, opQ, scales_type="dyadic", J=args.J)
+        if record: e[2].record()
+        Ws.backward(gs)
+        if record: e[3].record()
+        Wv.backward(gv)
+        if record: e[4].record()
+        if record: evs.append(e)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        per = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i, nm in enumerate(names)}
+        bytes_q = alg_bytes_vector(N, nnz, T, F)
+        bytes_p = alg_bytes_scalar(N, nnz, C, T, F)
+        achieved = bytes_q / (per["Q_fwd"] * 1e-3) / 1e9
+        out = {
+            "metric": "graphs/sec for P+Q scattering fwd+bwd (J=4)",
+            "value": args.graphs * world * args.steps / dt,
+            "unit": "graphs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: {args.graphs} ellipsoid graphs x {args.nodes} nodes per GPU, kNN k={args.k}, "
+                                   f"P (CSR, C=3) + Q (BSR-3) dyadic J={args.J} + lowpass, fwd+bwd",
+                       "graphs_per_gpu": args.graphs, "nodes_per_graph": args.nodes, "k": args.k, "J": args.J,
+                       "N": N, "nnz_P": nnz, "T": T, "F": F, "parallelism": f"dp{world} (graph shards, no data-path collective)"},
+            "roofline": {"bound": "hbm", "kernel": "k_chain_bsr3 (Q chain forward)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_q, "ms_per_launch": per["Q_fwd"],
+                         "regime": "operator (<=300 KB per graph) is re-read from L2/Infinity Cache after the first of the "
+                                   "T steps, so HBM traffic is below the algorithmic bytes (SURVEY.md 8d)"},
+            "kernels_ms": per,
+            "kernels_alg_GBs": {"P_fwd": bytes_p / (per["P_fwd"] * 1e-3) / 1e9, "Q_fwd": achieved,
+                                "P_bwd": bytes_p / (per["P_bwd"] * 1e-3) / 1e9,
+                                "Q_bwd": bytes_q / (per["Q_bwd"] * 1e-3) / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sample = min(args.cpu_sample_graphs, args.graphs)
+            gps1, s1 = cpu_baseline(b, sample, args.nodes, args.J, 1)
+            out["cpu_baseline"] = {"value": gps1, "unit": "graphs/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {sample} graphs of the same batch, fwd+bwd of both tracks, "
+                                             f"torch.sparse.mm COO restatement of the reference, {s1:.1f} s",
+                                   "host_cpus": os.cpu_count()}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

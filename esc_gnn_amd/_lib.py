@@ -1,0 +1,70 @@
+"""
+ctypes binding of libescat.so (the C ABI declared in include/escat.h).
+
+The library is built in-tree by `make -C esc_gnn_amd/csrc` (or
+__graft_entry__.build()).  There is NO fallback: if the shared object is
+missing or a symbol is absent, importing the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libescat.so")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+vp = ctypes.c_void_p
+i64 = ctypes.c_int64
+ci = ctypes.c_int
+sz = ctypes.c_size_t
+
+
+class EscatEvent(ctypes.Structure):
+    _fields_ = [("step", ctypes.c_int32), ("slot", ctypes.c_int32),
+                ("sign", ctypes.c_int32), ("chan", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/escat.h declares
+SIGNATURES = {
+    "escat_last_error": (ctypes.c_char_p, []),
+    "escat_abi_version": (ci, []),
+    "escat_csr_spmm_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp]),
+    "escat_bsr3_spmv_f32": (ci, [vp, vp, vp, i64, i64, vp, vp, vp]),
+    "escat_chain_workspace_bytes": (sz, [i64, ci]),
+    "escat_chain_csr_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
+    "escat_chain_csr_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
+    "escat_chain_bsr3_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
+    "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
+    "escat_scatter_orders_f32": (ci, [vp, vp, i64, ci, ci, vp, vp]),
+    "escat_scatter_orders_bwd_f32": (ci, [vp, vp, i64, ci, ci, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class EscatError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libescat.so and bind every declared entry point. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EscatError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C esc_gnn_amd/csrc` "
+            "(hipcc --offload-arch=gfx950) or __graft_entry__.build(). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().escat_last_error()
+        raise EscatError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,760 @@
+// escat.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for ESc-GNN's
+// diffusion-wavelet scattering chain.  See include/escat.h for the contract and
+// DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Kernel families
+//   k_csr_step / k_bsr3_step      one product y = A x over the whole operator with
+//                                 the wavelet bookkeeping fused into the epilogue
+//                                 (used for graphs too large for LDS: cfg3).
+//   k_chain_csr / k_chain_bsr3    one workgroup per diagonal block of the batch:
+//                                 vectors ping-pong in LDS for all T steps, the
+//                                 (rows, C, F) output slab is accumulated in LDS
+//                                 and written once, fully coalesced.
+// Lane mapping (wave = 64 lanes):
+//   CSR   G lanes per row (G = 4/8/16 by mean row length), lane = one nonzero,
+//         C accumulators per lane, xor-shuffle reduction inside the group.
+//   BSR-3 3*g lanes per block row (g = 3 or 7 -> 9 or 21 lanes, 7 or 3 block rows
+//         per wave, 63 live lanes): lane (k, a) owns row a of block k, loads its
+//         12 contiguous bytes; a wave therefore reads 36 B x consecutive blocks
+//         as one contiguous run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/escat.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+extern "C" const char *escat_last_error(void) { return g_err; }
+extern "C" int escat_abi_version(void) { return 1; }
+
+#define CHECK_LAUNCH(what)                                                              \
+    do { hipError_t e_ = hipGetLastError();                                             \
+         if (e_ != hipSuccess) return fail(ESCAT_ELAUNCH, "%s: %s", what, hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------ event tables (kernel arguments)
+struct Ev { int step, slot, sign, chan; };          // sign: +1/-1; bit 8 set (|0x100) = first touch of (slot,chan): store
+struct EvTable { int n; Ev e[ESCAT_MAX_EVENTS]; };  // whole chain (fused kernels)
+#define STEP_MAX_EV 24
+struct StepEv { int n; Ev e[STEP_MAX_EV]; };        // one step (multi-launch path)
+
+#define EV_STORE 0x100
+// encoding: bit0 = valid, bit1 = negative, bit8 = store
+static inline int enc_sign(int sign, bool store) { return 1 | (sign < 0 ? 2 : 0) | (store ? EV_STORE : 0); }
+
+// validates + encodes the host event list; marks the first event of every (slot, chan)
+static int build_table(const escat_event *ev, int n_ev, int T, int F, int C, EvTable *tab)
+{
+    if (n_ev < 0 || n_ev > ESCAT_MAX_EVENTS) return fail(ESCAT_ERANGE, "n_events=%d exceeds ESCAT_MAX_EVENTS", n_ev);
+    if (n_ev > 0 && !ev) return fail(ESCAT_EINVAL, "events is NULL");
+    if (F < 1 || F > 64) return fail(ESCAT_ERANGE, "F=%d out of range [1,64]", F);
+    static thread_local unsigned char seen[64 * ESCAT_MAX_CHANNELS];
+    memset(seen, 0, sizeof(seen));
+    tab->n = n_ev;
+    for (int k = 0; k < n_ev; ++k) {
+        if (ev[k].step < 0 || ev[k].step > T) return fail(ESCAT_EINVAL, "event %d: step %d outside [0,%d]", k, ev[k].step, T);
+        if (k && ev[k].step < ev[k - 1].step) return fail(ESCAT_EINVAL, "events not sorted by step");
+        if (ev[k].slot < 0 || ev[k].slot >= F) return fail(ESCAT_EINVAL, "event %d: slot %d outside [0,%d)", k, ev[k].slot, F);
+        if (ev[k].chan >= C) return fail(ESCAT_EINVAL, "event %d: chan %d >= C=%d", k, ev[k].chan, C);
+        if (ev[k].sign != 1 && ev[k].sign != -1) return fail(ESCAT_EINVAL, "event %d: sign must be +1/-1", k);
+        const int c0 = ev[k].chan < 0 ? 0 : ev[k].chan, c1 = ev[k].chan < 0 ? C : ev[k].chan + 1;
+        int touched = 0;
+        for (int c = c0; c < c1; ++c) touched += seen[ev[k].slot * ESCAT_MAX_CHANNELS + c];
+        if (touched != 0 && touched != c1 - c0)
+            return fail(ESCAT_EINVAL, "event %d mixes touched and untouched channels of slot %d", k, ev[k].slot);
+        const bool first = touched == 0;      // first touch of these OUT elements: store instead of accumulate
+        for (int c = c0; c < c1; ++c) seen[ev[k].slot * ESCAT_MAX_CHANNELS + c] = 1;
+        tab->e[k].step = ev[k].step; tab->e[k].slot = ev[k].slot; tab->e[k].chan = ev[k].chan;
+        tab->e[k].sign = enc_sign(ev[k].sign, first);
+    }
+    for (int f = 0; f < F; ++f)
+        for (int c = 0; c < C; ++c)
+            if (!seen[f * ESCAT_MAX_CHANNELS + c])
+                return fail(ESCAT_EINVAL, "OUT slot %d channel %d receives no event", f, c);
+    return ESCAT_OK;
+}
+
+static int step_events(const EvTable &tab, int step, StepEv *se)
+{
+    se->n = 0;
+    for (int k = 0; k < tab.n; ++k)
+        if (tab.e[k].step == step) {
+            if (se->n >= STEP_MAX_EV) return fail(ESCAT_ERANGE, "more than %d events at step %d", STEP_MAX_EV, step);
+            se->e[se->n++] = tab.e[k];
+        }
+    return ESCAT_OK;
+}
+
+// ------------------------------------------------------------------ device helpers
+template <int G> __device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// apply forward events of one step to element (row, c) whose fresh value is y
+__device__ __forceinline__ void emit_one(float *o /* &OUT[row, c, 0] */, float y, int slot, int s)
+{
+    if (s & EV_STORE) o[slot] = (s & 2) ? -y : y;
+    else o[slot] = (s & 2) ? o[slot] - y : o[slot] + y;
+}
+
+// ------------------------------------------------------------------ multi-launch path: scalar CSR
+// MODE 0: y = A x.   MODE 1: forward step (emit y into OUT).   MODE 2: backward step (y += gathered G).
+template <int C, int G, int MODE>
+__global__ void __launch_bounds__(256)
+k_csr_step(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
+           const float *__restrict__ xin, int ldx, float *__restrict__ yout, int ldy, int64_t n,
+           StepEv ev, float *OUT, int64_t ld_row, int F)
+{
+    const int lg = threadIdx.x % G;
+    const int64_t groups = (int64_t)gridDim.x * (256 / G);
+    for (int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; row < n; row += groups) {
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        const int e1 = rowptr[row + 1];
+        for (int e = rowptr[row] + lg; e < e1; e += G) {
+            const float v = val[e];
+            const float *x = xin + (int64_t)col[e] * ldx;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += v * x[c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = group_sum<G>(acc[c]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (c % G != lg) continue;          // lane c%G owns channel c
+            float y = acc[c];
+            if (MODE == 2) {
+                const float *g = OUT + row * ld_row + (int64_t)c * F;
+                for (int k = 0; k < ev.n; ++k)
+                    if (ev.e[k].chan < 0 || ev.e[k].chan == c) y += (ev.e[k].sign & 2) ? -g[ev.e[k].slot] : g[ev.e[k].slot];
+            }
+            yout[row * ldy + c] = y;
+            if (MODE == 1) {
+                float *o = OUT + row * ld_row + (int64_t)c * F;
+                for (int k = 0; k < ev.n; ++k)
+                    if (ev.e[k].chan < 0 || ev.e[k].chan == c) emit_one(o, y, ev.e[k].slot, ev.e[k].sign);
+            }
+        }
+    }
+}
+
+// elementwise: forward -> emit events of a step for the vector v itself (step 0);
+// backward -> v = sum of gathered G (the Horner start, or the whole answer when T == 0).
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_events_only(float *v, int ldv, int64_t n, int C, StepEv ev, float *OUT, int64_t ld_row, int F)
+{
+    const int64_t total = n * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C; const int c = (int)(i % C);
+        float *o = OUT + row * ld_row + (int64_t)c * F;
+        if (MODE == 1) {
+            const float y = v[row * ldv + c];
+            for (int k = 0; k < ev.n; ++k)
+                if (ev.e[k].chan < 0 || ev.e[k].chan == c) emit_one(o, y, ev.e[k].slot, ev.e[k].sign);
+        } else {
+            float y = 0.f;
+            for (int k = 0; k < ev.n; ++k)
+                if (ev.e[k].chan < 0 || ev.e[k].chan == c) y += (ev.e[k].sign & 2) ? -o[ev.e[k].slot] : o[ev.e[k].slot];
+            v[row * ldv + c] = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ multi-launch path: BSR-3
+template <int g, int MODE>
+__global__ void __launch_bounds__(256)
+k_bsr3_step(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
+            const float *__restrict__ xin, float *__restrict__ yout, int64_t nb,
+            StepEv ev, float *OUT, int F)
+{
+    constexpr int GL = 3 * g, RPW = 64 / GL;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / GL, l = lane % GL, k = l / 3, a = l % 3;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW; base < nb; base += waves * RPW) {
+        const int64_t brow = base + sub;
+        const bool live = sub < RPW && brow < nb;
+        float acc = 0.f;
+        if (live) {
+            const int e1 = rowptr[brow + 1];
+            for (int e = rowptr[brow] + k; e < e1; e += g) {
+                const float *b = blk + (int64_t)e * 9 + a * 3;
+                const float *x = xin + (int64_t)col[e] * 3;
+                acc += b[0] * x[0] + b[1] * x[1] + b[2] * x[2];
+            }
+        }
+        float tot = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < g; ++kk) {
+            const int src = live ? sub * GL + 3 * kk + a : lane;
+            tot += __shfl(acc, src, 64);
+        }
+        if (live && k == 0) {
+            const int64_t r = 3 * brow + a;
+            float y = tot;
+            if (MODE == 2) {
+                const float *gg = OUT + r * F;
+                for (int q = 0; q < ev.n; ++q) y += (ev.e[q].sign & 2) ? -gg[ev.e[q].slot] : gg[ev.e[q].slot];
+            }
+            yout[r] = y;
+            if (MODE == 1) {
+                float *o = OUT + r * F;
+                for (int q = 0; q < ev.n; ++q) emit_one(o, y, ev.e[q].slot, ev.e[q].sign);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fused per-part chains (vectors resident in LDS)
+// LDS layout (floats): xa[rows*C] | xb[rows*C] | slab[rows*C*F]
+// forward : slab accumulates OUT for the part, written once at the end.
+// backward: slab holds the part's upstream gradient, read-only.
+#define CHAIN_NT 256
+
+template <int C, int G, bool BWD>
+__global__ void __launch_bounds__(CHAIN_NT)
+k_chain_csr(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
+            const int *__restrict__ part_ptr, const float *__restrict__ X /* fwd: x, bwd: G */,
+            float *__restrict__ OUT /* fwd: OUT, bwd: dX */, int T, EvTable tab, int F)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int gs = part_ptr[blockIdx.x], rows = part_ptr[blockIdx.x + 1] - gs;
+    const int nc = rows * C;
+    float *xa = smem, *xb = smem + nc, *slab = smem + 2 * nc;
+    const int tid = threadIdx.x;
+    const int lg = tid % G, grp = tid / G;
+    constexpr int NGRP = CHAIN_NT / G;
+
+    if (!BWD) {
+        const float *xg = X + (int64_t)gs * C;
+        for (int i = tid; i < nc; i += CHAIN_NT) xa[i] = xg[i];
+    } else {
+        const float *gg = X + (int64_t)gs * C * F;
+        for (int i = tid; i < nc * F; i += CHAIN_NT) slab[i] = gg[i];
+    }
+    __syncthreads();
+
+    int p = BWD ? tab.n : 0;   // event cursor (uniform)
+    if (!BWD) {
+        // events at step 0 act on x itself
+        int p1 = p; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
+        for (int i = tid; i < nc; i += CHAIN_NT) {
+            const int c = i % C; const float y = xa[i];
+            for (int k = p; k < p1; ++k)
+                if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + (int64_t)i * F, y, tab.e[k].slot, tab.e[k].sign);
+        }
+        p = p1;
+    } else {
+        // Horner start: acc_T = sum of events at step T
+        int p0 = p; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
+        for (int i = tid; i < nc; i += CHAIN_NT) {
+            const int c = i % C; float y = 0.f;
+            for (int k = p0; k < p; ++k)
+                if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -slab[i * F + tab.e[k].slot] : slab[i * F + tab.e[k].slot];
+            xa[i] = y;
+        }
+        p = p0;
+    }
+    __syncthreads();
+
+    for (int t = 1; t <= T; ++t) {
+        // forward: this product yields y_t, events at step t.  backward: yields acc_{T-t}, events at step T-t.
+        const int st = BWD ? T - t : t;
+        int q0, q1;
+        if (!BWD) { q0 = p; q1 = p; while (q1 < tab.n && tab.e[q1].step == st) ++q1; p = q1; }
+        else { q1 = p; q0 = p; while (q0 > 0 && tab.e[q0 - 1].step == st) --q0; p = q0; }
+        for (int r = grp; r < rows; r += NGRP) {
+            float acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = 0.f;
+            const int e1 = rowptr[gs + r + 1];
+            for (int e = rowptr[gs + r] + lg; e < e1; e += G) {
+                const float v = val[e];
+                const float *x = xa + (col[e] - gs) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += v * x[c];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = group_sum<G>(acc[c]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (c % G != lg) continue;
+                float y = acc[c];
+                float *o = slab + (r * C + c) * F;
+                if (BWD) {
+                    for (int k = q0; k < q1; ++k)
+                        if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -o[tab.e[k].slot] : o[tab.e[k].slot];
+                } else {
+                    for (int k = q0; k < q1; ++k)
+                        if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(o, y, tab.e[k].slot, tab.e[k].sign);
+                }
+                xb[r * C + c] = y;
+            }
+        }
+        __syncthreads();
+        float *s = xa; xa = xb; xb = s;
+    }
+    if (!BWD) {
+        float *og = OUT + (int64_t)gs * C * F;
+        for (int i = tid; i < nc * F; i += CHAIN_NT) og[i] = slab[i];
+    } else {
+        float *dg = OUT + (int64_t)gs * C;
+        for (int i = tid; i < nc; i += CHAIN_NT) dg[i] = xa[i];
+    }
+}
+
+template <int g, bool BWD>
+__global__ void __launch_bounds__(CHAIN_NT)
+k_chain_bsr3(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
+             const int *__restrict__ part_ptr, const float *__restrict__ X, float *__restrict__ OUT,
+             int T, EvTable tab, int F)
+{
+    extern __shared__ __align__(16) float smem[];
+    constexpr int GL = 3 * g, RPW = 64 / GL, NW = CHAIN_NT / 64;
+    const int gs = part_ptr[blockIdx.x], brows = part_ptr[blockIdx.x + 1] - gs;
+    const int nc = brows * 3;
+    float *xa = smem, *xb = smem + nc, *slab = smem + 2 * nc;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sub = lane / GL, l = lane % GL, k = l / 3, a = l % 3;
+
+    if (!BWD) {
+        const float *xg = X + (int64_t)gs * 3;
+        for (int i = tid; i < nc; i += CHAIN_NT) xa[i] = xg[i];
+    } else {
+        const float *gg = X + (int64_t)gs * 3 * F;
+        for (int i = tid; i < nc * F; i += CHAIN_NT) slab[i] = gg[i];
+    }
+    __syncthreads();
+    int p = BWD ? tab.n : 0;
+    if (!BWD) {
+        int p1 = p; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
+        for (int i = tid; i < nc; i += CHAIN_NT) {
+            const float y = xa[i];
+            for (int q = p; q < p1; ++q) emit_one(slab + i * F, y, tab.e[q].slot, tab.e[q].sign);
+        }
+        p = p1;
+    } else {
+        int p0 = p; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
+        for (int i = tid; i < nc; i += CHAIN_NT) {
+            float y = 0.f;
+            for (int q = p0; q < p; ++q) y += (tab.e[q].sign & 2) ? -slab[i * F + tab.e[q].slot] : slab[i * F + tab.e[q].slot];
+            xa[i] = y;
+        }
+        p = p0;
+    }
+    __syncthreads();
+
+    for (int t = 1; t <= T; ++t) {
+        const int st = BWD ? T - t : t;
+        int q0, q1;
+        if (!BWD) { q0 = p; q1 = p; while (q1 < tab.n && tab.e[q1].step == st) ++q1; p = q1; }
+        else { q1 = p; q0 = p; while (q0 > 0 && tab.e[q0 - 1].step == st) --q0; p = q0; }
+        for (int base = wv * RPW; base < brows; base += NW * RPW) {
+            const int br = base + sub;
+            const bool live = sub < RPW && br < brows;
+            float acc = 0.f;
+            if (live) {
+                const int e1 = rowptr[gs + br + 1];
+                for (int e = rowptr[gs + br] + k; e < e1; e += g) {
+                    const float *b = blk + (int64_t)e * 9 + a * 3;
+                    const float *x = xa + (col[e] - gs) * 3;
+                    acc += b[0] * x[0] + b[1] * x[1] + b[2] * x[2];
+                }
+            }
+            float tot = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < g; ++kk) {
+                const int src = live ? sub * GL + 3 * kk + a : lane;
+                tot += __shfl(acc, src, 64);
+            }
+            if (live && k == 0) {
+                const int r = 3 * br + a;
+                float y = tot;
+                float *o = slab + r * F;
+                if (BWD) { for (int q = q0; q < q1; ++q) y += (tab.e[q].sign & 2) ? -o[tab.e[q].slot] : o[tab.e[q].slot]; }
+                else     { for (int q = q0; q < q1; ++q) emit_one(o, y, tab.e[q].slot, tab.e[q].sign); }
+                xb[r] = y;
+            }
+        }
+        __syncthreads();
+        float *s = xa; xa = xb; xb = s;
+    }
+    if (!BWD) {
+        float *og = OUT + (int64_t)gs * 3 * F;
+        for (int i = tid; i < nc * F; i += CHAIN_NT) og[i] = slab[i];
+    } else {
+        float *dg = OUT + (int64_t)gs * 3;
+        for (int i = tid; i < nc; i += CHAIN_NT) dg[i] = xa[i];
+    }
+}
+
+// ------------------------------------------------------------------ orders 0/1/2 epilogue (ESCGNNModular._scatter)
+__global__ void __launch_bounds__(256)
+k_scatter_orders(const float *__restrict__ x0, const float *__restrict__ W1, int64_t rows, int F, int Wtot,
+                 float *__restrict__ W)
+{
+    // one thread per output element; triu pair (i,j) of index q recovered by a short scan
+    const int64_t total = rows * Wtot;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx / Wtot; const int w = (int)(idx % Wtot);
+        float v;
+        if (w == 0) v = x0[r];
+        else if (w <= F) v = W1[r * F + (w - 1)];
+        else {
+            int q = w - 1 - F, i = 0, len = F - 1;
+            while (q >= len) { q -= len; ++i; --len; }
+            v = W1[r * F + i] * W1[r * F + i + 1 + q];
+        }
+        W[idx] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_scatter_orders_bwd(const float *__restrict__ W1, const float *__restrict__ dW, int64_t rows, int F, int Wtot,
+                     int second, float *__restrict__ dx0, float *__restrict__ dW1)
+{
+    const int64_t total = rows * F;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx / F; const int f = (int)(idx % F);
+        const float *d = dW + r * Wtot; const float *w1 = W1 + r * F;
+        if (f == 0) dx0[r] = d[0];
+        float g = d[1 + f];
+        if (second) {
+            int q = 1 + F;
+            for (int i = 0; i < F; ++i)
+                for (int j = i + 1; j < F; ++j, ++q) {
+                    if (i == f) g += d[q] * w1[j];
+                    else if (j == f) g += d[q] * w1[i];
+                }
+        }
+        dW1[idx] = g;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+static int grid_for(int64_t work_items, int per_block)
+{
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    const int64_t cap = 256 * 16;          // 256 CUs x 16 blocks, grid-stride beyond
+    return (int)(b < cap ? b : cap);
+}
+
+static int pick_G(int64_t n, int64_t nnz)
+{
+    const double mean = n > 0 ? (double)nnz / (double)n : 0.0;
+    return mean <= 6.0 ? 4 : (mean <= 24.0 ? 8 : 16);
+}
+static int pick_g(int64_t nb, int64_t nnzb)
+{
+    const double mean = nb > 0 ? (double)nnzb / (double)nb : 0.0;
+    return mean <= 4.5 ? 3 : 7;
+}
+
+template <int C, int MODE>
+static void launch_csr_step_G(int G, int grid_rows_hint, const int *rp, const int *ci, const float *v, const float *xin, int ldx,
+                              float *y, int ldy, int64_t n, const StepEv &ev, float *OUT, int64_t ld_row, int F, hipStream_t st)
+{
+    (void)grid_rows_hint;
+    if (G == 4)      hipLaunchKernelGGL((k_csr_step<C, 4, MODE>), dim3(grid_for(n, 64)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
+    else if (G == 8) hipLaunchKernelGGL((k_csr_step<C, 8, MODE>), dim3(grid_for(n, 32)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
+    else             hipLaunchKernelGGL((k_csr_step<C, 16, MODE>), dim3(grid_for(n, 16)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
+}
+
+template <int MODE>
+static int launch_csr_step(int C, int G, const int *rp, const int *ci, const float *v, const float *xin, int ldx,
+                           float *y, int ldy, int64_t n, const StepEv &ev, float *OUT, int64_t ld_row, int F, hipStream_t st)
+{
+    switch (C) {
+#define CASE(c) case c: launch_csr_step_G<c, MODE>(G, 0, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F, st); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+        default: return fail(ESCAT_ERANGE, "C=%d outside [1,%d]", C, ESCAT_MAX_CHANNELS);
+    }
+    return ESCAT_OK;
+}
+
+template <int MODE>
+static void launch_bsr3_step(int g, const int *rp, const int *ci, const float *blk, const float *xin, float *y,
+                             int64_t nb, const StepEv &ev, float *OUT, int F, hipStream_t st)
+{
+    if (g == 3) hipLaunchKernelGGL((k_bsr3_step<3, MODE>), dim3(grid_for(nb, 4 * 7)), dim3(256), 0, st, rp, ci, blk, xin, y, nb, ev, OUT, F);
+    else        hipLaunchKernelGGL((k_bsr3_step<7, MODE>), dim3(grid_for(nb, 4 * 3)), dim3(256), 0, st, rp, ci, blk, xin, y, nb, ev, OUT, F);
+}
+
+static int check_csr(const void *rp, const void *ci, const void *v, int64_t n, int64_t nnz)
+{
+    if (!rp || (nnz > 0 && (!ci || !v))) return fail(ESCAT_EINVAL, "operator pointer is NULL");
+    if (n < 0 || nnz < 0) return fail(ESCAT_EINVAL, "negative size");
+    if (n >= (int64_t)1 << 31 || nnz >= (int64_t)1 << 31) return fail(ESCAT_ERANGE, "n or nnz >= 2^31 (int32 indices)");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_csr_spmm_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
+                                  const float *X, int ldx, float *Y, int ldy, int C, void *stream)
+{
+    int rc = check_csr(rowptr, col, val, n, nnz); if (rc) return rc;
+    if (!X || !Y) return fail(ESCAT_EINVAL, "X or Y is NULL");
+    if (ldx < C || ldy < C) return fail(ESCAT_EINVAL, "leading dimension smaller than C");
+    if (n == 0) return ESCAT_OK;
+    StepEv ev; ev.n = 0;
+    rc = launch_csr_step<0>(C, pick_G(n, nnz), rowptr, col, val, X, ldx, Y, ldy, n, ev, nullptr, 0, 0, S(stream));
+    if (rc) return rc;
+    CHECK_LAUNCH("escat_csr_spmm_f32");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_bsr3_spmv_f32(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
+                                   const float *x, float *y, void *stream)
+{
+    int rc = check_csr(rowptr, col, blk, nb, nnzb); if (rc) return rc;
+    if (3 * nb >= (int64_t)1 << 31) return fail(ESCAT_ERANGE, "3*nb >= 2^31");
+    if (!x || !y) return fail(ESCAT_EINVAL, "x or y is NULL");
+    if (nb == 0) return ESCAT_OK;
+    StepEv ev; ev.n = 0;
+    launch_bsr3_step<0>(pick_g(nb, nnzb), rowptr, col, blk, x, y, nb, ev, nullptr, 0, S(stream));
+    CHECK_LAUNCH("escat_bsr3_spmv_f32");
+    return ESCAT_OK;
+}
+
+extern "C" size_t escat_chain_workspace_bytes(int64_t n_rows, int C)
+{
+    if (n_rows < 0 || C < 1) return 0;
+    const int cc = C < ESCAT_MAX_CHANNELS ? C : ESCAT_MAX_CHANNELS;
+    return (size_t)2 * (size_t)n_rows * (size_t)cc * sizeof(float);
+}
+
+#define LDS_BUDGET (160 * 1024)
+
+template <typename K> static int set_lds(K kern, size_t bytes)
+{
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    }
+    return ESCAT_OK;
+}
+
+template <int C, bool BWD>
+static int launch_chain_csr_G(int G, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
+                              const float *X, float *OUT, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    int rc;
+#define GO(GG)                                                                                         \
+    rc = set_lds(k_chain_csr<C, GG, BWD>, lds); if (rc) return rc;                                     \
+    hipLaunchKernelGGL((k_chain_csr<C, GG, BWD>), dim3(n_parts), dim3(CHAIN_NT), lds, st, rp, ci, v, pp, X, OUT, T, tab, F);
+    if (G == 4) { GO(4) } else if (G == 8) { GO(8) } else { GO(16) }
+#undef GO
+    return ESCAT_OK;
+}
+
+template <bool BWD>
+static int launch_chain_csr(int C, int G, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
+                            const float *X, float *OUT, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    switch (C) {
+#define CASE(c) case c: return launch_chain_csr_G<c, BWD>(G, rp, ci, v, pp, n_parts, lds, X, OUT, T, tab, F, st);
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    return fail(ESCAT_ERANGE, "C=%d outside [1,%d]", C, ESCAT_MAX_CHANNELS);
+}
+
+// shared driver for the scalar chain, forward (BWD=false: IN = X, RES = OUT) and backward (IN = G, RES = dX)
+template <bool BWD>
+static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
+                     const float *IN, int C, int T, const escat_event *events, int n_events, int F, float *RES,
+                     const int32_t *part_ptr, int n_parts, int max_part_rows,
+                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_csr(rowptr, col, val, n, nnz); if (rc) return rc;
+    if (!IN || !RES) return fail(ESCAT_EINVAL, "input or output pointer is NULL");
+    if (C < 1 || C > ESCAT_MAX_CHANNELS) return fail(ESCAT_ERANGE, "C=%d outside [1,%d]", C, ESCAT_MAX_CHANNELS);
+    if (T < 0 || T > 4096) return fail(ESCAT_ERANGE, "T=%d outside [0,4096]", T);
+    EvTable tab;
+    rc = build_table(events, n_events, T, F, C, &tab); if (rc) return rc;
+    if (n == 0) return ESCAT_OK;
+    hipStream_t st = S(stream);
+    const int G = pick_G(n, nnz);
+
+    if (part_ptr && n_parts > 0 && max_part_rows > 0) {
+        const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
+        if (lds <= LDS_BUDGET) {
+            rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
+            if (rc) return rc;
+            CHECK_LAUNCH("k_chain_csr");
+            return ESCAT_OK;
+        }
+    }
+    // multi-launch path
+    const size_t need = (size_t)2 * n * C * sizeof(float);
+    if (T > 0 && (!workspace || workspace_bytes < need))
+        return fail(ESCAT_EWORKSPACE, "workspace %zu B < %zu B needed", workspace_bytes, need);
+    float *wa = (float *)workspace, *wb = wa ? wa + n * C : nullptr;
+    const int64_t ld_row = (int64_t)C * F;
+    StepEv se;
+    if (!BWD) {
+        rc = step_events(tab, 0, &se); if (rc) return rc;
+        if (se.n) hipLaunchKernelGGL((k_events_only<1>), dim3(grid_for(n * C, 256)), dim3(256), 0, st,
+                                     const_cast<float *>(IN), C, n, C, se, RES, ld_row, F);
+        const float *xin = IN;
+        for (int t = 1; t <= T; ++t) {
+            rc = step_events(tab, t, &se); if (rc) return rc;
+            float *y = (t & 1) ? wa : wb;
+            rc = launch_csr_step<1>(C, G, rowptr, col, val, xin, C, y, C, n, se, RES, ld_row, F, st); if (rc) return rc;
+            xin = y;
+        }
+    } else {
+        float *Gm = const_cast<float *>(IN);
+        rc = step_events(tab, T, &se); if (rc) return rc;
+        float *acc = T == 0 ? RES : wa;
+        hipLaunchKernelGGL((k_events_only<2>), dim3(grid_for(n * C, 256)), dim3(256), 0, st, acc, C, n, C, se, Gm, ld_row, F);
+        const float *xin = acc;
+        for (int t = T; t >= 1; --t) {
+            rc = step_events(tab, t - 1, &se); if (rc) return rc;
+            float *y = (t == 1) ? RES : (((T - t) & 1) ? wa : wb);
+            rc = launch_csr_step<2>(C, G, rowptr, col, val, xin, C, y, C, n, se, Gm, ld_row, F, st); if (rc) return rc;
+            xin = y;
+        }
+        if (T == 0) { /* answer already in RES */ }
+    }
+    CHECK_LAUNCH("k_csr_step chain");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_chain_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
+                                   const float *X, int C, int T, const escat_event *events, int n_events, int F, float *OUT,
+                                   const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    return chain_csr<false>(rowptr, col, val, n, nnz, X, C, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows,
+                            workspace, workspace_bytes, stream);
+}
+
+extern "C" int escat_chain_csr_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, int64_t n, int64_t nnz,
+                                       const float *G, int C, int T, const escat_event *events, int n_events, int F, float *dX,
+                                       const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    return chain_csr<true>(rowptr_t, col_t, val_t, n, nnz, G, C, T, events, n_events, F, dX, part_ptr, n_parts, max_part_rows,
+                           workspace, workspace_bytes, stream);
+}
+
+template <bool BWD>
+static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
+                      const float *IN, int T, const escat_event *events, int n_events, int F, float *RES,
+                      const int32_t *part_ptr, int n_parts, int max_part_rows,
+                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_csr(rowptr, col, blk, nb, nnzb); if (rc) return rc;
+    if (3 * nb >= (int64_t)1 << 31) return fail(ESCAT_ERANGE, "3*nb >= 2^31");
+    if (!IN || !RES) return fail(ESCAT_EINVAL, "input or output pointer is NULL");
+    if (T < 0 || T > 4096) return fail(ESCAT_ERANGE, "T=%d outside [0,4096]", T);
+    EvTable tab;
+    rc = build_table(events, n_events, T, F, 1, &tab); if (rc) return rc;
+    if (nb == 0) return ESCAT_OK;
+    hipStream_t st = S(stream);
+    const int g = pick_g(nb, nnzb);
+    const int64_t n = 3 * nb;
+
+    if (part_ptr && n_parts > 0 && max_part_rows > 0) {
+        const size_t lds = (size_t)max_part_rows * 3 * (2 + F) * sizeof(float);
+        if (lds <= LDS_BUDGET) {
+#define GO(gg)                                                                                          \
+            rc = set_lds(k_chain_bsr3<gg, BWD>, lds); if (rc) return rc;                                \
+            hipLaunchKernelGGL((k_chain_bsr3<gg, BWD>), dim3(n_parts), dim3(CHAIN_NT), lds, st, rowptr, col, blk, part_ptr, IN, RES, T, tab, F);
+            if (g == 3) { GO(3) } else { GO(7) }
+#undef GO
+            CHECK_LAUNCH("k_chain_bsr3");
+            return ESCAT_OK;
+        }
+    }
+    const size_t need = (size_t)2 * n * sizeof(float);
+    if (T > 0 && (!workspace || workspace_bytes < need))
+        return fail(ESCAT_EWORKSPACE, "workspace %zu B < %zu B needed", workspace_bytes, need);
+    float *wa = (float *)workspace, *wb = wa ? wa + n : nullptr;
+    StepEv se;
+    if (!BWD) {
+        rc = step_events(tab, 0, &se); if (rc) return rc;
+        if (se.n) hipLaunchKernelGGL((k_events_only<1>), dim3(grid_for(n, 256)), dim3(256), 0, st,
+                                     const_cast<float *>(IN), 1, n, 1, se, RES, (int64_t)F, F);
+        const float *xin = IN;
+        for (int t = 1; t <= T; ++t) {
+            rc = step_events(tab, t, &se); if (rc) return rc;
+            float *y = (t & 1) ? wa : wb;
+            launch_bsr3_step<1>(g, rowptr, col, blk, xin, y, nb, se, RES, F, st);
+            xin = y;
+        }
+    } else {
+        float *Gm = const_cast<float *>(IN);
+        rc = step_events(tab, T, &se); if (rc) return rc;
+        float *acc = T == 0 ? RES : wa;
+        hipLaunchKernelGGL((k_events_only<2>), dim3(grid_for(n, 256)), dim3(256), 0, st, acc, 1, n, 1, se, Gm, (int64_t)F, F);
+        const float *xin = acc;
+        for (int t = T; t >= 1; --t) {
+            rc = step_events(tab, t - 1, &se); if (rc) return rc;
+            float *y = (t == 1) ? RES : (((T - t) & 1) ? wa : wb);
+            launch_bsr3_step<2>(g, rowptr, col, blk, xin, y, nb, se, Gm, F, st);
+            xin = y;
+        }
+    }
+    CHECK_LAUNCH("k_bsr3_step chain");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_chain_bsr3_f32(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
+                                    const float *x, int T, const escat_event *events, int n_events, int F, float *OUT,
+                                    const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                    void *workspace, size_t workspace_bytes, void *stream)
+{
+    return chain_bsr3<false>(rowptr, col, blk, nb, nnzb, x, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows,
+                             workspace, workspace_bytes, stream);
+}
+
+extern "C" int escat_chain_bsr3_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *blk_t, int64_t nb, int64_t nnzb,
+                                        const float *G, int T, const escat_event *events, int n_events, int F, float *dx,
+                                        const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    return chain_bsr3<true>(rowptr_t, col_t, blk_t, nb, nnzb, G, T, events, n_events, F, dx, part_ptr, n_parts, max_part_rows,
+                            workspace, workspace_bytes, stream);
+}
+
+extern "C" int escat_scatter_orders_f32(const float *x0, const float *W1, int64_t rows, int F, int second_order, float *W,
+                                        void *stream)
+{
+    if (!x0 || !W1 || !W) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (F < 1 || F > 64) return fail(ESCAT_ERANGE, "F=%d out of range [1,64]", F);
+    if (rows <= 0) return rows == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative rows");
+    const int Wtot = 1 + F + (second_order ? F * (F - 1) / 2 : 0);
+    hipLaunchKernelGGL(k_scatter_orders, dim3(grid_for(rows * Wtot, 256)), dim3(256), 0, S(stream), x0, W1, rows, F, Wtot, W);
+    CHECK_LAUNCH("k_scatter_orders");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_scatter_orders_bwd_f32(const float *W1, const float *dW, int64_t rows, int F, int second_order,
+                                            float *dx0, float *dW1, void *stream)
+{
+    if (!W1 || !dW || !dx0 || !dW1) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (F < 1 || F > 64) return fail(ESCAT_ERANGE, "F=%d out of range [1,64]", F);
+    if (rows <= 0) return rows == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative rows");
+    const int Wtot = 1 + F + (second_order ? F * (F - 1) / 2 : 0);
+    hipLaunchKernelGGL(k_scatter_orders_bwd, dim3(grid_for(rows * F, 256)), dim3(256), 0, S(stream), W1, dW, rows, F, Wtot,
+                       second_order, dx0, dW1);
+    CHECK_LAUNCH("k_scatter_orders_bwd");
+    return ESCAT_OK;
+}

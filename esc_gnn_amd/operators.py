@@ -1,0 +1,237 @@
+"""
+Operator ingest: torch sparse tensors -> the canonical device formats the
+kernels consume (include/escat.h).
+
+What arrives: P and Q as torch sparse COO, int64 indices,
+fp32 values, flagged un-coalesced, block-diagonal over the graphs of a PyG batch
+(models/escgnn_data_classes.py:20-27, :137-142); Q in block-emission order
+(process_pyg_data.py:847-857).  What the kernels want: int32 CSR sorted by
+(row, col) -- the order torch's own coalesce() gives, so the index structure is
+bit-identical to the reference's coalesced operator -- or BSR-3 for an operator
+made of 3x3 blocks, the transposed operator for the backward walk, and the row
+ranges closed under the operator's columns (the diagonal blocks) so that one
+workgroup can own one graph.
+
+The sort/unique calls here are torch device ops (plumbing, done once per
+operator and cached on the tensor object); the products themselves never touch
+torch.
+"""
+from typing import Optional
+import numpy as np
+import torch
+
+PART_TARGET_ROWS = 256      # merge consecutive diagonal blocks up to this many (scalar) rows per workgroup
+
+
+def _rowptr(rows: torch.Tensor, n: int) -> torch.Tensor:
+    cnt = torch.bincount(rows, minlength=n)
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(cnt, 0, out=rp[1:])
+    return rp.to(torch.int32)
+
+
+def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: int):
+    """
+    Boundaries of the finest partition of rows 0..n into consecutive ranges that
+    no entry leaves (cut after row r iff every row <= r has cols <= r and every
+    row > r has cols > r), then greedily merged up to `target` rows.
+    Returns (part_ptr int32 device tensor, n_parts, max_part_rows).
+    """
+    dev = rowptr.device
+    if n == 0:
+        return torch.zeros(1, dtype=torch.int32, device=dev), 0, 0
+    rp = rowptr.long()
+    ar = torch.arange(n, device=dev)
+    if col.numel() == 0:
+        lo = hi = ar
+    else:
+        nonempty = rp[1:] > rp[:-1]
+        cl = col.long()
+        lo = torch.where(nonempty, cl[rp[:-1].clamp(max=cl.numel() - 1)], ar)   # rows are sorted by column
+        hi = torch.where(nonempty, cl[(rp[1:] - 1).clamp(min=0)], ar)
+        lo = torch.minimum(lo, ar)
+        hi = torch.maximum(hi, ar)
+    pm = torch.cummax(hi, 0).values                       # max col over rows <= r
+    sm = torch.flip(torch.cummin(torch.flip(lo, [0]), 0).values, [0])   # min col over rows >= r
+    ok = pm[:-1] <= ar[:-1]
+    ok &= sm[1:] >= ar[1:]
+    cuts = (torch.nonzero(ok).flatten() + 1).cpu().numpy()
+    bounds = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    # greedy merge (host, O(#blocks), once per operator)
+    out = [0]
+    start = 0
+    for i in range(1, len(bounds)):
+        if bounds[i] - start > target and bounds[i - 1] > start:
+            out.append(int(bounds[i - 1])); start = int(bounds[i - 1])
+    out.append(n)
+    out = np.unique(np.asarray(out, dtype=np.int64))
+    max_rows = int(np.diff(out).max())
+    return torch.from_numpy(out.astype(np.int32)).to(dev), len(out) - 1, max_rows
+
+
+class _Csr:
+    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows")
+
+    def __init__(self, rowptr, col, val, n, parts=None):
+        self.rowptr, self.col, self.val, self.n = rowptr, col, val, n
+        self.nnz = int(col.numel())
+        if parts is None:
+            parts = _closed_row_ranges(rowptr, col, n, PART_TARGET_ROWS)
+        self.part_ptr, self.n_parts, self.max_part_rows = parts
+
+
+class ScatterOperator:
+    """
+    Canonical device form of a diffusion operator (P or Q).  Built once from a
+    torch sparse tensor (from_torch) or from arrays already in CSR / BSR-3
+    (from_csr / from_bsr3); the transposed forms are built on first backward.
+
+    Attributes (device tensors): csr.{rowptr,col,val}; bsr.{rowptr,col,val}
+    where val is (nnzb,3,3); *.part_ptr the closed row ranges.
+    """
+
+    def __init__(self, n: int, device):
+        self.n = int(n)                 # scalar rows
+        self.device = device
+        self._csr: Optional[_Csr] = None
+        self._csr_t: Optional[_Csr] = None
+        self._bsr: Optional[_Csr] = None
+        self._bsr_t: Optional[_Csr] = None
+        self._coo = None                # (rows, cols, vals) coalesced, int64: source for lazy forms
+        self.bsr_fill = 0.0
+
+    # ---------------------------------------------------------------- constructors
+    @staticmethod
+    def from_torch(A: torch.Tensor, allow_cpu: bool = False) -> "ScatterOperator":
+        # allow_cpu exists for host-logic tests of the canonical index structure only;
+        # get_Batch_Wjxs refuses CPU tensors.
+        if not A.is_cuda and not allow_cpu:
+            raise RuntimeError("escat: the operator must live on a GPU (no CPU fallback in the product path)")
+        if A.dim() != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError(f"escat: square 2-D operator expected, got {tuple(A.shape)}")
+        n = A.shape[0]
+        if A.layout == torch.sparse_csr:
+            crow, col, val = A.crow_indices(), A.col_indices(), A.values()
+            rows = torch.repeat_interleave(torch.arange(n, device=A.device), crow[1:] - crow[:-1])
+            key = rows * n + col.long()
+            if key.numel() > 1 and not bool((key[1:] > key[:-1]).all()):
+                A = A.to_sparse_coo().coalesce()
+                rows, col, val = A.indices()[0], A.indices()[1], A.values()
+        elif A.layout == torch.sparse_coo:
+            if not A.is_coalesced():
+                A = A.coalesce()
+            rows, col, val = A.indices()[0], A.indices()[1], A.values()
+        else:
+            raise TypeError(f"escat: unsupported operator layout {A.layout}")
+        op = ScatterOperator(n, A.device)
+        op._coo = (rows.long(), col.long(), val.to(torch.float32))
+        if n % 3 == 0 and op._coo[0].numel() > 0:
+            op._try_bsr3()
+        return op
+
+    @staticmethod
+    def from_csr(rowptr, col, val, n, validate=True, parts=None) -> "ScatterOperator":
+        op = ScatterOperator(n, val.device)
+        rowptr, col = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+        if validate:
+            _validate(rowptr, col, n)
+        op._csr = _Csr(rowptr, col, val.to(torch.float32).contiguous(), n, parts)
+        return op
+
+    @staticmethod
+    def from_bsr3(rowptr, col, blk, nb, validate=True, parts=None) -> "ScatterOperator":
+        op = ScatterOperator(3 * nb, blk.device)
+        rowptr, col = rowptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+        if validate:
+            _validate(rowptr, col, nb)
+        if blk.shape[1:] != (3, 3):
+            raise ValueError("blk must be (nnzb, 3, 3)")
+        op._bsr = _Csr(rowptr, col, blk.to(torch.float32).contiguous(), nb, parts)
+        op.bsr_fill = 1.0
+        return op
+
+    # ---------------------------------------------------------------- forms
+    def _try_bsr3(self):
+        rows, cols, vals = self._coo
+        nb = self.n // 3
+        bkey = (rows // 3) * nb + (cols // 3)
+        ub, inv = torch.unique(bkey, return_inverse=True)
+        nnzb = int(ub.numel())
+        self.bsr_fill = rows.numel() / (9.0 * nnzb)
+        if self.bsr_fill < 0.5:
+            return
+        blk = torch.zeros(nnzb * 9, dtype=torch.float32, device=vals.device)
+        blk.index_put_((inv * 9 + (rows % 3) * 3 + (cols % 3),), vals)
+        brow = ub // nb
+        self._bsr = _Csr(_rowptr(brow, nb), (ub % nb).to(torch.int32), blk.view(nnzb, 3, 3), nb)
+
+    @property
+    def has_bsr3(self) -> bool:
+        return self._bsr is not None
+
+    def csr(self) -> _Csr:
+        if self._csr is None:
+            if self._coo is not None:
+                rows, cols, vals = self._coo
+                self._csr = _Csr(_rowptr(rows, self.n), cols.to(torch.int32), vals.contiguous(), self.n)
+            else:   # expand BSR-3 to scalar CSR
+                b = self._bsr
+                rp = b.rowptr.long()
+                brow = torch.repeat_interleave(torch.arange(b.n, device=self.device), rp[1:] - rp[:-1])
+                a = torch.arange(3, device=self.device)
+                rows = (3 * brow)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]
+                cols = (3 * b.col.long())[:, None, None] + 0 * a[None, :, None] + a[None, None, :]
+                key = (rows * self.n + cols).reshape(-1)
+                order = torch.argsort(key)
+                rows, cols, vals = rows.reshape(-1)[order], cols.reshape(-1)[order], b.val.reshape(-1)[order]
+                self._csr = _Csr(_rowptr(rows, self.n), cols.to(torch.int32), vals.contiguous(), self.n)
+        return self._csr
+
+    def bsr3(self) -> _Csr:
+        if self._bsr is None:
+            raise RuntimeError("operator has no BSR-3 form")
+        return self._bsr
+
+    def csr_t(self) -> _Csr:
+        if self._csr_t is None:
+            c = self.csr()
+            rp = c.rowptr.long()
+            rows = torch.repeat_interleave(torch.arange(c.n, device=self.device), rp[1:] - rp[:-1])
+            order = torch.argsort(c.col.long() * c.n + rows)
+            self._csr_t = _Csr(_rowptr(c.col.long()[order], c.n), rows[order].to(torch.int32),
+                               c.val[order].contiguous(), c.n)
+        return self._csr_t
+
+    def bsr3_t(self) -> _Csr:
+        if self._bsr_t is None:
+            b = self.bsr3()
+            rp = b.rowptr.long()
+            rows = torch.repeat_interleave(torch.arange(b.n, device=self.device), rp[1:] - rp[:-1])
+            order = torch.argsort(b.col.long() * b.n + rows)
+            self._bsr_t = _Csr(_rowptr(b.col.long()[order], b.n), rows[order].to(torch.int32),
+                               b.val[order].transpose(1, 2).contiguous(), b.n)
+        return self._bsr_t
+
+
+def _validate(rowptr, col, n):
+    if rowptr.numel() != n + 1:
+        raise ValueError("rowptr must have n+1 entries")
+    rp = rowptr.long()
+    if int(rp[0]) != 0 or int(rp[-1]) != col.numel() or bool((rp[1:] < rp[:-1]).any()):
+        raise ValueError("rowptr is not a monotone prefix ending at nnz")
+    if col.numel() and (int(col.min()) < 0 or int(col.max()) >= n):
+        raise ValueError("column index out of range")
+
+
+def as_operator(P_sparse) -> ScatterOperator:
+    """torch sparse tensor (or a ScatterOperator) -> ScatterOperator, cached on the tensor object."""
+    if isinstance(P_sparse, ScatterOperator):
+        return P_sparse
+    op = getattr(P_sparse, "_escat_operator", None)
+    if op is None:
+        op = ScatterOperator.from_torch(P_sparse)
+        try:
+            P_sparse._escat_operator = op
+        except Exception:
+            pass
+    return op

@@ -1,0 +1,134 @@
+"""
+Drop-in for the reference's pyg_utilities.get_Batch_Wjxs
+(/root/reference/pyg_utilities.py:283-560): same name, same arguments, same
+return layout, same error behaviour -- computed by libescat.so's gfx950 kernels.
+
+    from esc_gnn_amd.pyg_utilities import get_Batch_Wjxs
+
+There is no CPU path: tensors must live on the GPU and the HIP library must be
+built, otherwise this raises.
+"""
+import ctypes
+from typing import Optional
+import torch
+
+from . import _lib
+from .operators import ScatterOperator, as_operator
+from .scales import ChainPlan, plan_chain
+
+LDS_BUDGET = 160 * 1024
+MAX_C = 8
+
+
+def _events_array(events):
+    arr = (_lib.EscatEvent * max(len(events), 1))()
+    for k, (step, slot, sign, chan) in enumerate(events):
+        arr[k].step, arr[k].slot, arr[k].sign, arr[k].chan = step, slot, sign, chan
+    return arr
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else 0) if t is not None else ctypes.c_void_p(0)
+
+
+def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool) -> torch.Tensor:
+    """one call into the C ABI for <= MAX_C channels.  inp: fwd (n,C) / bwd (n,C,F); returns fwd (n,C,F) / bwd (n,C)."""
+    lib = _lib.load()
+    dev = inp.device
+    n = op.n
+    ev = _events_array(plan_events)
+    use_bsr = C == 1 and op.has_bsr3
+    form = (op.bsr3_t() if backward else op.bsr3()) if use_bsr else (op.csr_t() if backward else op.csr())
+    rows_per = 3 if use_bsr else 1
+    out = torch.empty((n, C) if backward else (n, C, F), dtype=torch.float32, device=dev)
+    lds = form.max_part_rows * rows_per * C * (2 + F) * 4
+    fused = form.n_parts > 0 and lds <= LDS_BUDGET
+    ws = None
+    if not fused and T > 0:
+        ws = torch.empty(lib.escat_chain_workspace_bytes(n, C) // 4, dtype=torch.float32, device=dev)
+    ws_bytes = ws.numel() * 4 if ws is not None else 0
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        if use_bsr:
+            fn = lib.escat_chain_bsr3_bwd_f32 if backward else lib.escat_chain_bsr3_f32
+            rc = fn(_ptr(form.rowptr), _ptr(form.col), _ptr(form.val), form.n, form.nnz, _ptr(inp), T,
+                    ctypes.cast(ev, ctypes.c_void_p), len(plan_events), F, _ptr(out),
+                    _ptr(form.part_ptr), form.n_parts, form.max_part_rows, _ptr(ws), ws_bytes, st)
+        else:
+            fn = lib.escat_chain_csr_bwd_f32 if backward else lib.escat_chain_csr_f32
+            rc = fn(_ptr(form.rowptr), _ptr(form.col), _ptr(form.val), form.n, form.nnz, _ptr(inp), C, T,
+                    ctypes.cast(ev, ctypes.c_void_p), len(plan_events), F, _ptr(out),
+                    _ptr(form.part_ptr), form.n_parts, form.max_part_rows, _ptr(ws), ws_bytes, st)
+    _lib.check(rc, fn.__name__ if hasattr(fn, "__name__") else "escat chain")
+    return out
+
+
+def _run_chain(op: ScatterOperator, plan: ChainPlan, inp: torch.Tensor, backward: bool) -> torch.Tensor:
+    C = inp.shape[1]
+    if C <= MAX_C:
+        return _chain_launch(op, plan.events, plan.T, plan.F, inp.contiguous(), C, backward)
+    # wider feature matrices: column chunks of <= MAX_C channels (per-channel events are re-based per chunk)
+    outs = []
+    for c0 in range(0, C, MAX_C):
+        c1 = min(C, c0 + MAX_C)
+        evs = tuple((s, f, sg, ch if ch < 0 else ch - c0) for (s, f, sg, ch) in plan.events if ch < 0 or c0 <= ch < c1)
+        outs.append(_chain_launch(op, evs, plan.T, plan.F, inp[:, c0:c1].contiguous(), c1 - c0, backward))
+    return torch.cat(outs, dim=1)
+
+
+class _WaveletBank(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op, plan):
+        ctx.op, ctx.plan = op, plan
+        return _run_chain(op, plan, x, backward=False)
+
+    @staticmethod
+    def backward(ctx, gW):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        return _run_chain(ctx.op, ctx.plan, gW.contiguous(), backward=True), None, None
+
+
+def get_Batch_Wjxs(
+    x: torch.Tensor,
+    P_sparse,
+    scales_type='dyadic',
+    diffusion_scales=None,
+    J: int = 5,
+    include_lowpass: bool = True,
+    filter_stack_dim: int = -1,
+    rescale_filtrations: bool = False,
+) -> torch.Tensor:
+    """
+    Diffusion-wavelet filter bank W_j x = (P^{a_{j-1}} - P^{a_j}) x (+ low-pass)
+    by recursive sparse products; see pyg_utilities.py:283-347 of the reference
+    for the argument semantics, which are unchanged.  `P_sparse` may be a torch
+    sparse COO/CSR tensor (canonicalised once and cached on the tensor) or a
+    prebuilt esc_gnn_amd.ScatterOperator.  Returns (N, C, F), fp32, on x.device,
+    differentiable w.r.t. x.
+    """
+    plan = plan_chain(scales_type=scales_type, diffusion_scales=diffusion_scales, J=J,
+                      include_lowpass=include_lowpass)
+    if rescale_filtrations:
+        raise NotImplementedError("Rescaling filtrations within 'get_Batch_Wjxs' has been deprecated.")
+    if not torch.is_tensor(x) or x.dim() != 2:
+        raise ValueError("escat: x must be a 2-D (N, C) tensor")
+    if not x.is_cuda:
+        raise RuntimeError("escat: x must live on a GPU; the MI355X path has no CPU fallback "
+                           "(use the reference implementation on CPU)")
+    if x.dtype != torch.float32:
+        raise TypeError(f"escat: x must be float32 (torch.sparse.mm in the reference requires matching fp32), got {x.dtype}")
+    op = as_operator(P_sparse)
+    if op.n != x.shape[0]:
+        raise RuntimeError(f"escat: size mismatch, operator is {op.n}x{op.n} but x has {x.shape[0]} rows")
+    if plan.per_channel and plan.n_channels != x.shape[1]:
+        raise IndexError("index out of range: per-channel diffusion_scales rows != channels of x")
+    W = _WaveletBank.apply(x, op, plan)
+    if not plan.per_channel and plan.T >= 0 and filter_stack_dim not in (-1, 2) \
+            and not (diffusion_scales is None and scales_type is None):
+        W = W.movedim(-1, filter_stack_dim)
+    return W

@@ -1,0 +1,96 @@
+"""
+Host logic: turn the arguments of get_Batch_Wjxs into a chain plan
+(T, F, event table) for the device kernels.
+
+Every mode of the reference function (pyg_utilities.py:283-560) keeps some
+powers y_t = P^t x and differences neighbours of that list; a plan states that
+as events {step, slot, sign, chan} (include/escat.h).  Quirks reproduced on
+purpose:
+  * custom 1-D scales loop to scales[-1] and keep power j once per occurrence of
+    j in `scales` (:363-375); Ptxs always starts with x itself, so when
+    scales[0] != 0 the list is one longer than `scales` and the last band is
+    never formed (:381 with range_upper_lim = len(scales));
+  * 2-D per-channel scales run to 2**J regardless of the scales and take the
+    low-pass from P^(2**J) (:399-402, :437-442);
+  * the string 'dyadic' as diffusion_scales falls through to dyadic (:392-394,
+    :448-450, :464);
+  * scales_type=None with no scales is the single product P^1 x (:476-479).
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+import torch
+
+
+@dataclass(frozen=True)
+class ChainPlan:
+    T: int
+    F: int
+    events: Tuple[Tuple[int, int, int, int], ...]   # (step, slot, sign, chan), sorted by step
+    per_channel: bool = False
+    n_channels: Optional[int] = None                # fixed by a 2-D scales tensor
+
+
+def _as_int_list(t) -> List:
+    if torch.is_tensor(t):
+        return t.detach().cpu().tolist()
+    return list(t)
+
+
+def plan_chain(scales_type='dyadic', diffusion_scales=None, J=5, include_lowpass=True) -> ChainPlan:
+    ds = diffusion_scales
+    is_dyadic_str = isinstance(ds, str) and ds == 'dyadic'
+    if ds is not None and not is_dyadic_str and isinstance(ds, str):
+        raise NotImplementedError(f"No method implemented for scales_type={scales_type}")
+    ndim = None
+    if ds is not None and not is_dyadic_str:
+        ndim = ds.dim() if torch.is_tensor(ds) else (2 if len(ds) and isinstance(ds[0], (list, tuple)) else 1)
+
+    events = []
+    if ndim == 2:
+        rows = _as_int_list(ds)
+        T = int(2 ** J)
+        F = 0
+        for c, t_is in enumerate(rows):
+            for i in range(1, len(t_is)):
+                for t in (t_is[i - 1], t_is[i]):
+                    if not 0 <= int(t) <= T:
+                        raise IndexError("list index out of range")
+                events.append((int(t_is[i - 1]), i - 1, +1, c))
+                events.append((int(t_is[i]), i - 1, -1, c))
+            F = max(F, len(t_is) - 1)
+        if include_lowpass:
+            events.append((T, F, +1, -1))
+            F += 1
+        events.sort(key=lambda e: e[0])
+        T = max([e[0] for e in events], default=0)     # powers beyond the last one used are never read
+        return ChainPlan(T, F, tuple(events), True, len(rows))
+
+    if ndim == 1:
+        powers = [int(v) for v in _as_int_list(ds)]
+        upper = len(powers)
+    elif scales_type == 'dyadic':
+        powers = [2 ** j for j in range(J + 1)]
+        upper = J + 2
+    elif ds is None and scales_type is None:
+        return ChainPlan(1, 1, ((1, 0, +1, -1),))
+    else:
+        raise NotImplementedError(f"No method implemented for scales_type={scales_type}")
+
+    T = max(int(powers[-1]), 0) if powers else 0
+    kept = [0]
+    for j in range(1, T + 1):
+        kept += [j] * powers.count(j)
+    if upper - 1 > len(kept) - 1:
+        raise IndexError("list index out of range")
+    F = 0
+    for j in range(1, upper):
+        events.append((kept[j - 1], F, +1, -1))
+        events.append((kept[j], F, -1, -1))
+        F += 1
+    if include_lowpass:
+        events.append((kept[-1], F, +1, -1))
+        F += 1
+    if F == 0:
+        raise RuntimeError("stack expects a non-empty TensorList")   # what torch.stack([]) raises in the reference
+    events.sort(key=lambda e: e[0])          # stable: + before - inside a slot when powers coincide
+    return ChainPlan(kept[-1], F, tuple(events))

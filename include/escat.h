@@ -1,0 +1,141 @@
+/*
+ * escat.h -- C ABI of libescat.so: MI355X (gfx950) kernels for ESc-GNN's
+ * diffusion-wavelet scattering hot path.
+ *
+ * The reference (dj408/esc-gnn) has no FFI layer: its boundary for this path is
+ * the Python function pyg_utilities.get_Batch_Wjxs (pyg_utilities.py:283-560)
+ * and, one level up, ESCGNNModular._scatter (models/escgnn_modular.py:309-362).
+ * Each entry point below names the reference lines whose work it replaces; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and is what
+ * esc_gnn_amd/_lib.py does.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every array pointer is a DEVICE pointer
+ *     unless the parameter comment says "host";
+ *   - returns 0 on success, a negative ESCAT_E* code otherwise; the message is
+ *     available from escat_last_error() (thread-local); no C++ exception
+ *     crosses the boundary;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream), no internal synchronisation, no hidden allocation:
+ *     scratch memory comes in through the workspace arguments;
+ *   - int32 indices (nnz < 2^31 is checked), fp32 values, row-major dense
+ *     operands.
+ *
+ * Operator formats
+ *   CSR   rowptr[n+1], col[nnz], val[nnz]; rows sorted by column (the order a
+ *         coalesced torch COO has).
+ *   BSR-3 rowptr[nb+1], col[nnzb], blk[nnzb][3][3]: block (i,j) covers scalar
+ *         rows 3i..3i+2 / cols 3j..3j+2; this is the vector-track operator Q
+ *         (process_pyg_data.py:823-868 emits exactly one 3x3 block per P-nnz).
+ *
+ * Event table (how every mode of get_Batch_Wjxs is expressed)
+ *   The chain visits y_t = A^t x for t = 0..T.  For every event
+ *   {step, slot, sign, chan}: OUT[:, c, slot] (+|-)= y_step[:, c] for c = chan
+ *   (or all channels when chan < 0).  A wavelet band Ptxs[f] - Ptxs[f+1]
+ *   (pyg_utilities.py:381) is a + event at the first power and a - event at
+ *   the second; the low-pass (:383) is a single + event.  Events must be
+ *   sorted by step; every (slot, channel) of OUT must receive at least one
+ *   event (OUT is not cleared).
+ */
+#ifndef ESCAT_H
+#define ESCAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESCAT_OK            0
+#define ESCAT_EINVAL       -1   /* bad argument (null pointer, size, unsorted events, ...) */
+#define ESCAT_ERANGE       -2   /* size beyond what the kernels support */
+#define ESCAT_EWORKSPACE   -3   /* workspace too small */
+#define ESCAT_ELAUNCH      -4   /* HIP reported a launch error */
+
+#define ESCAT_MAX_EVENTS   160
+#define ESCAT_MAX_CHANNELS 8    /* per launch; the host side chunks wider X */
+
+typedef struct { int32_t step, slot, sign, chan; } escat_event;
+
+/* last error message of the calling thread ("" if none). */
+const char *escat_last_error(void);
+/* ABI version, bumped when a signature changes. */
+int escat_abi_version(void);
+
+/* Y = A X.  Replaces one torch.sparse.mm(P_sparse, Ptx) call
+ * (pyg_utilities.py:365, :401, :478).  X is (n, C) with row stride ldx,
+ * Y (n, C) with row stride ldy, 1 <= C <= ESCAT_MAX_CHANNELS. */
+int escat_csr_spmm_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                       int64_t n, int64_t nnz, const float *X, int ldx, float *Y, int ldy,
+                       int C, void *stream);
+
+/* y = Q x, Q in BSR-3, x and y of length 3*nb.  Replaces torch.sparse.mm(Q, v)
+ * on the vector track (models/escgnn_modular.py:345-351 -> pyg_utilities.py:365). */
+int escat_bsr3_spmv_f32(const int32_t *rowptr, const int32_t *col, const float *blk,
+                        int64_t nb, int64_t nnzb, const float *x, float *y, void *stream);
+
+/* bytes of workspace the chain entry points need for n scalar rows and C
+ * channels when they take the multi-launch path (two ping-pong vectors). */
+size_t escat_chain_workspace_bytes(int64_t n_rows, int C);
+
+/* Forward filter bank, scalar track.  Replaces the whole of
+ * _get_Wjxs_from_shared_powers (pyg_utilities.py:350-385), the per-channel
+ * variant (:392-444) and the P^1 case (:476-479): T products, the kept powers,
+ * the differences and the stack, written once into OUT (n, C, F) contiguous.
+ *   events       host pointer, n_events <= ESCAT_MAX_EVENTS, sorted by step.
+ *   part_ptr     device int32[n_parts+1] or NULL: row ranges that are closed
+ *                under the operator's columns (the diagonal blocks of a PyG
+ *                batch, models/escgnn_data_classes.py:20-27).  When given and
+ *                max_part_rows fits the LDS budget, each range is processed by
+ *                one workgroup with the vectors resident in LDS for all T
+ *                steps; otherwise T step kernels run over the whole operator
+ *                using `workspace`.
+ */
+int escat_chain_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                        int64_t n, int64_t nnz, const float *X, int C, int T,
+                        const escat_event *events, int n_events, int F, float *OUT,
+                        const int32_t *part_ptr, int n_parts, int max_part_rows,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward of the above w.r.t. X (what autograd of the reference's chain
+ * computes when x.requires_grad): dX = sum_events sign * (A^T)^step G[:, chan, slot].
+ * Takes the TRANSPOSED operator in CSR (rows of A^T sorted by column) and the
+ * upstream gradient G (n, C, F) contiguous. */
+int escat_chain_csr_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *val_t,
+                            int64_t n, int64_t nnz, const float *G, int C, int T,
+                            const escat_event *events, int n_events, int F, float *dX,
+                            const int32_t *part_ptr, int n_parts, int max_part_rows,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* Forward filter bank, vector track: x is the (3*nb,) flattening of (nb, 3)
+ * node vectors (models/escgnn_modular.py:345), OUT is (3*nb, 1, F) contiguous
+ * (what get_Batch_Wjxs returns for x of shape (3N, 1)).  part_ptr counts
+ * BLOCK rows. */
+int escat_chain_bsr3_f32(const int32_t *rowptr, const int32_t *col, const float *blk,
+                         int64_t nb, int64_t nnzb, const float *x, int T,
+                         const escat_event *events, int n_events, int F, float *OUT,
+                         const int32_t *part_ptr, int n_parts, int max_part_rows,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward of the vector-track bank; takes Q^T in BSR-3 (block (j,i) of Q^T is
+ * the transpose of block (i,j) of Q). */
+int escat_chain_bsr3_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *blk_t,
+                             int64_t nb, int64_t nnzb, const float *G, int T,
+                             const escat_event *events, int n_events, int F, float *dx,
+                             const int32_t *part_ptr, int n_parts, int max_part_rows,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* Orders 0/1/2 of ESCGNNModular._scatter (models/escgnn_modular.py:333-341,
+ * :355-360): W (rows, Wtot) = [x0 | W1 | W1[i]*W1[j] for i<j in triu order
+ * (:507-516)], Wtot = 1 + F + (second_order ? F(F-1)/2 : 0).  rows = n*C. */
+int escat_scatter_orders_f32(const float *x0, const float *W1, int64_t rows, int F,
+                             int second_order, float *W, void *stream);
+/* its backward: dW (rows, Wtot) -> dx0 (rows,), dW1 (rows, F). */
+int escat_scatter_orders_bwd_f32(const float *W1, const float *dW, int64_t rows, int F,
+                                 int second_order, float *dx0, float *dW1, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESCAT_H */

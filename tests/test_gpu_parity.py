@@ -1,0 +1,287 @@
+"""
+GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through
+the C ABI of libescat.so via the drop-in Python signatures and is compared with
+  (1) the golden vectors generated from the real reference (tests/golden/),
+  (2) the CPU oracle (oracle/) on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at the benchmark sizes.
+Tolerance (BASELINE.json north_star): fp32 relative 1e-5, taken per filter as
+max|delta| <= 1e-5 * max|ref| (wavelets are differences of nearly equal vectors,
+SURVEY.md §7), index structure bit-exact.
+"""
+import ctypes
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain_oracle as co
+from tests.test_oracle import MODES
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(a, ref, rtol=RTOL):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    for f in range(ref.shape[-1]):
+        d = np.abs(a[..., f] - ref[..., f]).max()
+        assert d <= rtol * np.abs(ref[..., f]).max() + 1e-30, (f, d, np.abs(ref[..., f]).max())
+
+
+def _ops(sg, dev):
+    N = int(sg["N"])
+    P = torch.sparse_coo_tensor(torch.from_numpy(sg["P_indices"]), torch.from_numpy(sg["P_values"]), (N, N),
+                                dtype=torch.float32).to(dev)
+    Q = torch.sparse_coo_tensor(torch.from_numpy(sg["Q_indices"]), torch.from_numpy(sg["Q_values"]), (3 * N, 3 * N),
+                                dtype=torch.float32).to(dev)
+    return N, P, Q
+
+
+def test_library_loaded_and_native():
+    from esc_gnn_amd import _lib
+    lib = _lib.load()
+    assert lib.escat_abi_version() == 1
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_get_Batch_Wjxs_vs_goldens(sg, mode):
+    from esc_gnn_amd import get_Batch_Wjxs
+    dev = _dev()
+    N, P, Q = _ops(sg, dev)
+    kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in MODES[mode].items()}
+    for C in (1, 3, 5):
+        x = torch.from_numpy(sg[f"x_C{C}"]).to(dev).requires_grad_(True)
+        W = get_Batch_Wjxs(x, P, **kw)
+        assert W.is_cuda and W.dtype == torch.float32 and W.is_contiguous()
+        _close(W, sg[f"P_{mode}_C{C}_W"])
+        (W * torch.from_numpy(sg[f"P_{mode}_C{C}_gup"]).to(dev)).sum().backward()
+        _close(x.grad, sg[f"P_{mode}_C{C}_gx"], rtol=2e-5)
+    xv = torch.from_numpy(sg["x_v"]).to(dev).reshape(3 * N, 1).requires_grad_(True)
+    W = get_Batch_Wjxs(xv, Q, **kw)
+    _close(W, sg[f"Q_{mode}_W"])
+    (W * torch.from_numpy(sg[f"Q_{mode}_gup"]).to(dev)).sum().backward()
+    _close(xv.grad, sg[f"Q_{mode}_gx"], rtol=2e-5)
+
+
+def test_perchannel_and_wide_C(sg):
+    from esc_gnn_amd import get_Batch_Wjxs
+    dev = _dev()
+    N, P, _ = _ops(sg, dev)
+    ds2 = torch.from_numpy(sg["perchan_scales"]).to(dev)
+    for lp in (True, False):
+        W = get_Batch_Wjxs(torch.from_numpy(sg["x_C3"]).to(dev), P, scales_type="custom", diffusion_scales=ds2, J=3,
+                           include_lowpass=lp)
+        _close(W, sg[f"P_perchan_lp{int(lp)}_C3_W"])
+    # C = 11 > 8 channels per launch: column chunks; compare with the torch.sparse restatement on CPU
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, 11, generator=g)
+    ref = co.ref_get_Batch_Wjxs(x, P.cpu(), scales_type="dyadic", J=3)
+    xg = x.to(dev).requires_grad_(True)
+    W = get_Batch_Wjxs(xg, P, scales_type="dyadic", J=3)
+    _close(W, ref.numpy())
+    gup = torch.randn(ref.shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    (co.ref_get_Batch_Wjxs(xr, P.cpu(), scales_type="dyadic", J=3) * gup).sum().backward()
+    (W * gup.to(dev)).sum().backward()
+    _close(xg.grad, xr.grad.numpy(), rtol=2e-5)
+
+
+def test_vs_fp64_dense_reference(sg):
+    """both the reference (goldens) and the kernels sit within fp32 noise of the fp64 dense-power bank."""
+    from esc_gnn_amd import get_Batch_Wjxs
+    dev = _dev()
+    N, P, Q = _ops(sg, dev)
+    W = get_Batch_Wjxs(torch.from_numpy(sg["x_C3"]).to(dev), P, J=4).cpu().numpy().astype(np.float64)
+    r64 = sg["f64_P_dyadic_J4_C3_W"]
+    ours = np.abs(W - r64).max(axis=(0, 1)) / np.abs(r64).max(axis=(0, 1))
+    theirs = np.abs(sg["P_dyadic_J4_C3_W"] - r64).max(axis=(0, 1)) / np.abs(r64).max(axis=(0, 1))
+    assert ours.max() < 5e-6 and ours.max() < 10 * max(theirs.max(), 1e-7)
+    Wq = get_Batch_Wjxs(torch.from_numpy(sg["x_v"]).to(dev).reshape(-1, 1), Q, J=4).cpu().numpy().astype(np.float64)
+    r64 = sg["f64_Q_dyadic_J4_W"]
+    assert (np.abs(Wq - r64).max(axis=(0, 1)) / np.abs(r64).max(axis=(0, 1))).max() < 5e-6
+
+
+def test_scatter_vs_goldens(sg):
+    from esc_gnn_amd import scatter, escat_scatter
+    dev = _dev()
+    N, P, Q = _ops(sg, dev)
+    kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=4, include_lowpass=True, diffusion_scales="dyadic")}
+    xs, xv = torch.from_numpy(sg["x_C3"]).to(dev), torch.from_numpy(sg["x_v"]).to(dev)
+    for abl in (False, True):
+        Ws = scatter(track="scalar", x0=xs, P_or_Q=P, kwargs=kw, ablate_second_order_wavelets=abl)
+        Wv = scatter(track="vector", x0=xv, P_or_Q=Q, kwargs=kw, ablate_second_order_wavelets=abl)
+        rs, rv = sg[f"scatter_scalar_abl{int(abl)}"], sg[f"scatter_vector_abl{int(abl)}"]
+        assert Ws.shape == rs.shape and Wv.shape == rv.shape
+        assert np.array_equal(Ws[..., 0].cpu().numpy(), rs[..., 0])            # order 0 is the input, bit for bit
+        assert np.abs(Ws.cpu().numpy() - rs).max() <= 2e-5 * np.abs(rs).max()
+        assert np.abs(Wv.cpu().numpy() - rv).max() <= 2e-5 * np.abs(rv).max()
+
+    class M:
+        ablate_second_order_wavelets = False
+    kwc = {"diffusion_kwargs": dict(scales_type="custom", J=4, include_lowpass=True,
+                                    diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16]))}
+    Wc = escat_scatter(M(), track="scalar", x0=xs, P_or_Q=P, kwargs=kwc)
+    rc = sg["scatter_scalar_custom"]
+    assert Wc.shape == rc.shape and np.abs(Wc.cpu().numpy() - rc).max() <= 2e-5 * np.abs(rc).max()
+    # gradient of the orders-0/1/2 epilogue against torch autograd of the same formula
+    xs2 = xs.clone().requires_grad_(True)
+    W = scatter(track="scalar", x0=xs2, P_or_Q=P, kwargs=kw)
+    gup = torch.randn(W.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    (W * gup).sum().backward()
+    xr = torch.from_numpy(sg["x_C3"]).requires_grad_(True)
+    Pc = P.cpu()
+    (co.ref_scatter("scalar", xr, Pc, kw["diffusion_kwargs"]) * gup.cpu()).sum().backward()
+    assert np.abs(xs2.grad.cpu().numpy() - xr.grad.numpy()).max() <= 5e-5 * np.abs(xr.grad.numpy()).max()
+
+
+def test_single_products_and_errors(sg):
+    """K1 / K2 entry points called straight through ctypes; error codes instead of faults."""
+    from esc_gnn_amd import _lib, ScatterOperator
+    dev = _dev()
+    lib = _lib.load()
+    N, P, Q = _ops(sg, dev)
+    opP, opQ = ScatterOperator.from_torch(P), ScatterOperator.from_torch(Q)
+    c, b = opP.csr(), opQ.bsr3()
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for C in (1, 3, 5, 8):
+        x = torch.randn(N, C, device=dev)
+        y = torch.empty(N, C, device=dev)
+        rc = lib.escat_csr_spmm_f32(c.rowptr.data_ptr(), c.col.data_ptr(), c.val.data_ptr(), N, c.nnz,
+                                    x.data_ptr(), C, y.data_ptr(), C, C, st)
+        assert rc == 0
+        ref = torch.sparse.mm(P.cpu(), x.cpu())
+        assert (y.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    xv = torch.randn(3 * N, device=dev)
+    yv = torch.empty(3 * N, device=dev)
+    assert lib.escat_bsr3_spmv_f32(b.rowptr.data_ptr(), b.col.data_ptr(), b.val.data_ptr(), N, b.nnz,
+                                   xv.data_ptr(), yv.data_ptr(), st) == 0
+    ref = torch.sparse.mm(Q.cpu(), xv.cpu()[:, None])[:, 0]
+    assert (yv.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    # bad arguments come back as codes with a message
+    assert lib.escat_csr_spmm_f32(c.rowptr.data_ptr(), c.col.data_ptr(), c.val.data_ptr(), N, c.nnz,
+                                  x.data_ptr(), 8, y.data_ptr(), 8, 9, st) == -2
+    assert b"outside" in lib.escat_last_error()
+    assert lib.escat_csr_spmm_f32(None, None, None, N, c.nnz, x.data_ptr(), 8, y.data_ptr(), 8, 8, st) == -1
+
+
+def _random_batch(dev, B, n, k, seed):
+    from esc_gnn_amd import synthetic, ScatterOperator
+    b = synthetic.ellipsoid_batch(B, n, k, seed=seed)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    return b, opP, opQ
+
+
+@pytest.mark.parametrize("B,n,k,J", [(6, 200, 5, 4), (3, 500, 10, 4), (1, 3000, 16, 6), (40, 7, 3, 2)])
+def test_vs_c_oracle_seeded(oracle_lib, B, n, k, J):
+    """seeded ellipsoid batches vs the plain-C oracle: fused LDS path (small graphs), multi-launch path
+    (n = 3000 does not fit LDS), tiny ragged graphs (n = 7 merged many per workgroup)."""
+    from esc_gnn_amd import get_Batch_Wjxs, plan_chain
+    dev = _dev()
+    b, opP, opQ = _random_batch(dev, B, n, k, seed=100 + n)
+    plan = plan_chain(scales_type="dyadic", J=J)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    g = torch.Generator().manual_seed(n)
+    xs = torch.randn(b["N"], 3, generator=g)
+    W = get_Batch_Wjxs(xs.to(dev).requires_grad_(True), opP, J=J)
+    ref = co.c_chain_csr(b["rowptr"], b["col"], b["pval"], xs.numpy(), ev, plan.T, plan.F)
+    _close(W, ref)
+    gup = torch.randn(W.shape, generator=g)
+    xg = xs.to(dev).requires_grad_(True)
+    (get_Batch_Wjxs(xg, opP, J=J) * gup.to(dev)).sum().backward()
+    _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gup.numpy(), ev, plan.T), rtol=2e-5)
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    xvg = xv.to(dev).requires_grad_(True)
+    Wq = get_Batch_Wjxs(xvg, opQ, J=J)
+    refq = co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F)
+    _close(Wq, refq)
+    gq = torch.randn(Wq.shape, generator=g)
+    (Wq * gq.to(dev)).sum().backward()
+    _close(xvg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T), rtol=2e-5)
+
+
+def test_fused_and_multilaunch_paths_agree():
+    """same operator with and without row ranges -> LDS-fused kernel vs T step kernels."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(8, 300, 10, seed=9)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    none = (torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
+    x = torch.randn(b["N"], 3, device=dev)
+    xv = t(b["pos"]).reshape(-1, 1)
+    for kw in (dict(J=4), dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16]))):
+        Wf = get_Batch_Wjxs(x, ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"]), **kw)
+        Wm = get_Batch_Wjxs(x, ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"], parts=none), **kw)
+        assert (Wf - Wm).abs().max() <= 1e-6 * Wf.abs().max()    # same lane mapping and summation order
+        Qf = get_Batch_Wjxs(xv, ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"]), **kw)
+        Qm = get_Batch_Wjxs(xv, ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"], parts=none), **kw)
+        assert (Qf - Qm).abs().max() <= 1e-6 * Qf.abs().max()
+
+
+def test_properties_at_benchmark_size():
+    """BASELINE cfg2 shape at reduced B (256 x 500, k=10): size-independent properties.
+      * P is row-stochastic: constant input -> every band 0, low-pass = the constant;
+      * linearity: W(a x + b y) = a W(x) + b W(y);
+      * telescoping: sum of bands + low-pass = x;
+      * adjointness: <W(x), G> = <x, W^T(G)> ties backward to forward;
+      * frameless Q = P (x) I_3 reproduces the scalar track on coordinate columns."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(256, 500, 10, seed=457893, with_q=True)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    N = b["N"]
+    W1 = get_Batch_Wjxs(torch.full((N, 2), 3.0, device=dev), opP, J=4)
+    assert W1[..., :-1].abs().max() < 1e-5 and (W1[..., -1] - 3.0).abs().max() < 1e-5
+    x, y = torch.randn(N, 3, device=dev), torch.randn(N, 3, device=dev)
+    Wx, Wy = get_Batch_Wjxs(x, opP, J=4), get_Batch_Wjxs(y, opP, J=4)
+    Wl = get_Batch_Wjxs(2.0 * x - 0.5 * y, opP, J=4)
+    assert (Wl - (2.0 * Wx - 0.5 * Wy)).abs().max() <= 1e-5 * Wl.abs().max()
+    assert (Wx.sum(-1) - x).abs().max() < 2e-5
+    for op, xin in ((opP, x), (opQ, t(b["pos"]).reshape(-1, 1))):
+        xin = xin.clone().requires_grad_(True)
+        W = get_Batch_Wjxs(xin, op, J=4)
+        G = torch.randn_like(W)
+        (W * G).sum().backward()
+        lhs = (W.detach().double() * G.double()).sum()
+        rhs = (xin.detach().double() * xin.grad.double()).sum()
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+    Wq = get_Batch_Wjxs(t(b["pos"]).reshape(-1, 1), opQ, J=4)
+    assert (Wq.sum(-1).reshape(-1) - t(b["pos"]).reshape(-1)).abs().max() < 2e-5
+    eye = (t(b["pval"])[:, None, None] * torch.eye(3, device=dev)).contiguous()
+    opI = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), eye, N)
+    Wi = get_Batch_Wjxs(x.reshape(-1, 1), opI, J=4).reshape(N, 3, -1)
+    assert (Wi - Wx).abs().max() <= 1e-5 * Wx.abs().max()
+
+
+def test_empty_and_degenerate_inputs():
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator
+    dev = _dev()
+    # identity operator with isolated rows (rows of A = 0 -> P = I/2 ... here just diag), T = 0 plan, 1-node graphs
+    n = 5
+    rowptr = torch.arange(n + 1, dtype=torch.int32, device=dev)
+    col = torch.arange(n, dtype=torch.int32, device=dev)
+    op = ScatterOperator.from_csr(rowptr, col, torch.full((n,), 0.5, device=dev), n)
+    x = torch.arange(n * 2, dtype=torch.float32, device=dev).reshape(n, 2)
+    W = get_Batch_Wjxs(x, op, J=2)                       # powers 0,1,2,4 of I/2
+    exp = torch.stack([x - x / 2, x / 2 - x / 4, x / 4 - x / 16, x / 16], -1)
+    assert torch.equal(W, exp)
+    W0 = get_Batch_Wjxs(x, op, scales_type="custom", diffusion_scales=torch.tensor([0]))
+    assert torch.equal(W0, x.unsqueeze(-1))
+    # operator with an empty row
+    rowptr = torch.tensor([0, 1, 1, 2], dtype=torch.int32, device=dev)
+    col = torch.tensor([0, 2], dtype=torch.int32, device=dev)
+    op = ScatterOperator.from_csr(rowptr, col, torch.ones(2, device=dev), 3)
+    W = get_Batch_Wjxs(torch.ones(3, 1, device=dev), op, scales_type=None, diffusion_scales=None)
+    assert W.reshape(-1).tolist() == [1.0, 0.0, 1.0]
+    with pytest.raises(RuntimeError):
+        get_Batch_Wjxs(torch.ones(4, 1, device=dev), op, J=1)      # size mismatch
+    with pytest.raises(TypeError):
+        get_Batch_Wjxs(torch.ones(3, 1, device=dev, dtype=torch.float64), op, J=1)

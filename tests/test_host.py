@@ -1,0 +1,190 @@
+"""
+CPU tests of the product's host logic (no GPU, no kernel launches):
+  * the chain planner (esc_gnn_amd/scales.py) drives the C ORACLE to the golden
+    numbers of every mode -> the event tables the kernels receive are right;
+  * operator ingest (esc_gnn_amd/operators.py) gives the bit-exact CSR / BSR-3
+    index structure of the oracle's canonicalisation, correct transposes and
+    closed row ranges;
+  * libescat.so loads and exports every symbol include/escat.h declares.
+"""
+import os
+import re
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain_oracle as co
+from esc_gnn_amd.scales import plan_chain
+from esc_gnn_amd.operators import ScatterOperator, _closed_row_ranges
+from esc_gnn_amd import synthetic
+
+from tests.test_oracle import MODES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ev(plan):
+    return np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_plan_drives_oracle_to_goldens(sg, oracle_lib, mode):
+    N = int(sg["N"])
+    rp, ci, v = co.coo_to_csr(sg["P_indices"], sg["P_values"], N)
+    plan = plan_chain(**MODES[mode])
+    for C in (1, 3, 5):
+        ref = sg[f"P_{mode}_C{C}_W"]
+        W = co.c_chain_csr(rp, ci, v, sg[f"x_C{C}"], _ev(plan), plan.T, plan.F)
+        assert W.shape == ref.shape
+        assert np.abs(W - ref).max() <= 1e-5 * np.abs(ref).max()
+        gx = co.c_chain_csr_bwd(rp, ci, v, sg[f"P_{mode}_C{C}_gup"], _ev(plan), plan.T)
+        assert np.abs(gx - sg[f"P_{mode}_C{C}_gx"]).max() <= 1e-5 * np.abs(sg[f"P_{mode}_C{C}_gx"]).max()
+
+
+def test_plan_perchannel(sg, oracle_lib):
+    N = int(sg["N"])
+    rp, ci, v = co.coo_to_csr(sg["P_indices"], sg["P_values"], N)
+    for lp in (True, False):
+        plan = plan_chain(scales_type="custom", diffusion_scales=torch.from_numpy(sg["perchan_scales"]), J=3,
+                          include_lowpass=lp)
+        assert plan.per_channel and plan.n_channels == 3
+        W = co.c_chain_csr(rp, ci, v, sg["x_C3"], _ev(plan), plan.T, plan.F)
+        ref = sg[f"P_perchan_lp{int(lp)}_C3_W"]
+        assert W.shape == ref.shape and np.abs(W - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_plan_matches_oracle_tables():
+    for kw in MODES.values():
+        plan = plan_chain(**kw)
+        ev, T, F = co.events_for_mode(3, **kw)
+        assert (plan.F, sorted(plan.events)) == (F, sorted(map(tuple, ev.tolist())))
+        assert plan.T <= T
+
+
+def test_plan_errors():
+    with pytest.raises(NotImplementedError):
+        plan_chain(scales_type="bogus")
+    with pytest.raises(NotImplementedError):
+        plan_chain(scales_type="custom", diffusion_scales="dyadic")
+    with pytest.raises(IndexError):                 # too few kept powers for the band count (reference: list index)
+        plan_chain(scales_type="custom", diffusion_scales=torch.tensor([0, 0, 1]))
+    p = plan_chain(scales_type="custom", diffusion_scales=torch.tensor([0]))   # lowpass = x itself
+    assert (p.T, p.F, p.events) == (0, 1, ((0, 0, 1, -1),))
+    p = plan_chain(scales_type="custom", diffusion_scales=torch.tensor([1, 2, 4]))
+    assert p.F == 3 and p.T == 4                     # x-P, P-P^2, lowpass P^4: the P^2-P^4 band is dropped
+    assert (2, 1, -1, -1) in p.events and (4, 2, 1, -1) in p.events and (4, 1, -1, -1) not in p.events
+
+
+def test_ingest_index_structure_bit_exact(sg):
+    N = int(sg["N"])
+    P = torch.sparse_coo_tensor(torch.from_numpy(sg["P_indices"]), torch.from_numpy(sg["P_values"]), (N, N))
+    Q = torch.sparse_coo_tensor(torch.from_numpy(sg["Q_indices"]), torch.from_numpy(sg["Q_values"]), (3 * N, 3 * N))
+    assert not P.is_coalesced()
+    opP = ScatterOperator.from_torch(P, allow_cpu=True)
+    rp, ci, v = co.coo_to_csr(sg["P_indices"], sg["P_values"], N)
+    c = opP.csr()
+    assert c.rowptr.dtype == torch.int32 and c.col.dtype == torch.int32
+    assert np.array_equal(c.rowptr.numpy(), rp) and np.array_equal(c.col.numpy(), ci) and np.array_equal(c.val.numpy(), v)
+    assert not opP.has_bsr3                                     # P is not made of dense 3x3 blocks
+    opQ = ScatterOperator.from_torch(Q, allow_cpu=True)
+    brp, bci, blk = co.coo_to_bsr3(sg["Q_indices"], sg["Q_values"], 3 * N)
+    assert opQ.has_bsr3 and opQ.bsr_fill == 1.0
+    b = opQ.bsr3()
+    assert np.array_equal(b.rowptr.numpy(), brp) and np.array_equal(b.col.numpy(), bci)
+    assert np.array_equal(b.val.numpy(), blk)
+    assert np.array_equal(b.rowptr.numpy(), rp) and np.array_equal(b.col.numpy(), ci)    # Q sits on P's pattern
+    # scalar CSR of Q agrees with the oracle's too
+    qrp, qci, qv = co.coo_to_csr(sg["Q_indices"], sg["Q_values"], 3 * N)
+    cq = opQ.csr()
+    assert np.array_equal(cq.rowptr.numpy(), qrp) and np.array_equal(cq.col.numpy(), qci) and np.array_equal(cq.val.numpy(), qv)
+    # closed row ranges = the graphs of the batch (32 + 64 + 48 nodes; merged up to 256 rows -> one part)
+    assert c.n_parts >= 1 and int(c.part_ptr[-1]) == N
+    pp, npart, mx = _closed_row_ranges(c.rowptr, c.col, N, target=1)
+    assert np.array_equal(pp.numpy(), sg["graph_ptr"].astype(np.int32)) and mx == 64
+    # CSR input (what the probe in SURVEY §8c used) canonicalises to the same thing
+    opc = ScatterOperator.from_torch(P.coalesce().to_sparse_csr(), allow_cpu=True)
+    assert np.array_equal(opc.csr().col.numpy(), ci) and np.array_equal(opc.csr().val.numpy(), v)
+
+
+def test_ingest_transposes(sg):
+    N = int(sg["N"])
+    P = torch.sparse_coo_tensor(torch.from_numpy(sg["P_indices"]), torch.from_numpy(sg["P_values"]), (N, N))
+    Q = torch.sparse_coo_tensor(torch.from_numpy(sg["Q_indices"]), torch.from_numpy(sg["Q_values"]), (3 * N, 3 * N))
+    opP = ScatterOperator.from_torch(P, allow_cpu=True)
+    t = opP.csr_t()
+    dense_t = torch.sparse_csr_tensor(t.rowptr.long(), t.col.long(), t.val, (N, N)).to_dense()
+    assert torch.equal(dense_t, P.to_dense().T)
+    opQ = ScatterOperator.from_torch(Q, allow_cpu=True)
+    bt = opQ.bsr3_t()
+    Qt = torch.zeros(3 * N, 3 * N)
+    rp = bt.rowptr.numpy()
+    for i in range(N):
+        for e in range(rp[i], rp[i + 1]):
+            j = int(bt.col[e])
+            Qt[3 * i:3 * i + 3, 3 * j:3 * j + 3] = bt.val[e]
+    assert torch.equal(Qt, Q.to_dense().T)
+    # BSR-only operator can be expanded to scalar CSR
+    b = opQ.bsr3()
+    op2 = ScatterOperator.from_bsr3(b.rowptr, b.col, b.val, N)
+    c2, cq = op2.csr(), opQ.csr()
+    assert torch.equal(c2.rowptr, cq.rowptr) and torch.equal(c2.col, cq.col) and torch.equal(c2.val, cq.val)
+
+
+def test_row_ranges_edge_cases():
+    # empty rows, a dense coupling block, and a long chain that can never be cut
+    rowptr = torch.tensor([0, 1, 1, 3, 5, 6], dtype=torch.int32)      # row 1 empty
+    col = torch.tensor([0, 2, 3, 2, 3, 4], dtype=torch.int32)
+    pp, n, mx = _closed_row_ranges(rowptr, col, 5, target=1)
+    assert pp.tolist() == [0, 1, 2, 4, 5] and mx == 2
+    pp, n, mx = _closed_row_ranges(rowptr, col, 5, target=3)
+    assert pp.tolist()[0] == 0 and pp.tolist()[-1] == 5 and mx <= 3
+    n = 50
+    rows = torch.arange(n).repeat_interleave(2)[1:-1]
+    cols = torch.stack([torch.arange(n - 1), torch.arange(1, n)], 1).reshape(-1)
+    A = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(rows.numel()), (n, n))
+    op = ScatterOperator.from_torch(A, allow_cpu=True)
+    assert op.csr().n_parts == 1 and op.csr().max_part_rows == n
+    with pytest.raises(ValueError):
+        ScatterOperator.from_csr(torch.tensor([0, 2, 1]), torch.tensor([0, 1]), torch.ones(2), 2)
+    with pytest.raises(ValueError):
+        ScatterOperator.from_csr(torch.tensor([0, 1, 2]), torch.tensor([0, 5]), torch.ones(2), 2)
+    with pytest.raises(RuntimeError):
+        ScatterOperator.from_torch(A)          # CPU operator refused on the product path
+
+
+def test_synthetic_batch_matches_reference_P(bg):
+    """synthetic.lazy_walk_values == get_P of the reference on the golden graphs (bit-exact)."""
+    for ci, c in enumerate(bg["cases"]):
+        n, k = int(str(c).split(",")[0]), int(str(c).split(",")[1])
+        rp, col = synthetic.knn_sym_csr(bg[f"g{ci}_pos"], k)
+        Pi = bg[f"g{ci}_P_indices"]
+        assert np.array_equal(col, Pi[1]) and rp[-1] == Pi.shape[1]
+        assert np.array_equal(synthetic.lazy_walk_values(rp, col), bg[f"g{ci}_P_values_f32"])
+    b = synthetic.ellipsoid_batch(3, 40, 5)
+    R = b["blk"] / b["pval"][:, None, None]
+    assert np.abs(np.einsum("eab,ecb->eac", R, R) - np.eye(3)).max() < 1e-5
+
+
+def test_library_exports_every_declared_symbol():
+    from esc_gnn_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "escat.h")).read()
+    declared = set(re.findall(r"\b(escat_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.escat_abi_version() == 1
+    assert lib.escat_chain_workspace_bytes(1000, 3) == 2 * 1000 * 3 * 4
+
+
+def test_product_path_refuses_cpu(sg):
+    from esc_gnn_amd import get_Batch_Wjxs
+    N = int(sg["N"])
+    P = torch.sparse_coo_tensor(torch.from_numpy(sg["P_indices"]), torch.from_numpy(sg["P_values"]), (N, N))
+    with pytest.raises(RuntimeError):
+        get_Batch_Wjxs(torch.from_numpy(sg["x_C3"]), P, J=2)
+    with pytest.raises(NotImplementedError):
+        get_Batch_Wjxs(torch.from_numpy(sg["x_C3"]), P, scales_type="nope")
+    with pytest.raises(NotImplementedError):
+        get_Batch_Wjxs(torch.from_numpy(sg["x_C3"]), P, J=2, rescale_filtrations=True)
