@@ -164,7 +164,7 @@ def test_single_products_and_errors(sg):
     assert (yv.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
     # bad arguments come back as codes with a message
     assert lib.escat_csr_spmm_f32(c.rowptr.data_ptr(), c.col.data_ptr(), c.val.data_ptr(), N, c.nnz,
-                                  x.data_ptr(), 8, y.data_ptr(), 8, 9, st) == -2
+                                  x.data_ptr(), 9, y.data_ptr(), 9, 9, st) == -2
     assert b"outside" in lib.escat_last_error()
     assert lib.escat_csr_spmm_f32(None, None, None, N, c.nnz, x.data_ptr(), 8, y.data_ptr(), 8, 8, st) == -1
 
