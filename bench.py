@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--J", type=int, default=4)
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-workers", type=int, default=-1,
+                    help="processes for input generation (-1: up to 16; use 1 under rocprofv3: no fork after GPU init)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,7 +98,7 @@ def main():
 
     # ---- inputs (host, before the GPU is touched: the generator forks workers)
     from esc_gnn_amd import synthetic
-    workers = min(16, os.cpu_count() or 1)
+    workers = min(16, os.cpu_count() or 1) if args.gen_workers < 0 else args.gen_workers
     b = synthetic.ellipsoid_batch(args.graphs, args.nodes, args.k, seed=457892 + 1 + rank, workers=workers)
     N, nnz = b["N"], b["nnz"]
 
