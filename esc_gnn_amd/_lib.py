@@ -24,6 +24,12 @@ class EscatEvent(ctypes.Structure):
                 ("sign", ctypes.c_int32), ("chan", ctypes.c_int32)]
 
 
+class EscatSell(ctypes.Structure):
+    _fields_ = [("val", ctypes.c_void_p), ("lc", ctypes.c_void_p), ("perm", ctypes.c_void_p),
+                ("slice_doff", ctypes.c_void_p), ("slice_poff", ctypes.c_void_p), ("part_slice_ptr", ctypes.c_void_p),
+                ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/escat.h declares
 SIGNATURES = {
     "escat_last_error": (ctypes.c_char_p, []),
@@ -31,10 +37,10 @@ SIGNATURES = {
     "escat_csr_spmm_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp]),
     "escat_bsr3_spmv_f32": (ci, [vp, vp, vp, i64, i64, vp, vp, vp]),
     "escat_chain_workspace_bytes": (sz, [i64, ci]),
-    "escat_chain_csr_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
-    "escat_chain_csr_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
-    "escat_chain_bsr3_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
-    "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, sz, vp]),
+    "escat_chain_csr_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
+    "escat_chain_csr_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
+    "escat_chain_bsr3_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
+    "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_scatter_orders_f32": (ci, [vp, vp, i64, ci, ci, vp, vp]),
     "escat_scatter_orders_bwd_f32": (ci, [vp, vp, i64, ci, ci, vp, vp, vp]),
 }

@@ -22,6 +22,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/escat.h"
 
 // ------------------------------------------------------------------ errors
@@ -400,6 +401,276 @@ k_chain_bsr3(const int *__restrict__ rowptr, const int *__restrict__ col, const 
     }
 }
 
+// ------------------------------------------------------------------ register-resident chains
+// One thread owns one row of its part for the whole chain: the row's first DMAX
+// entries (values + packed 16-bit local column offsets) live in VGPRs across all T
+// steps, so the operator is read from HBM exactly ONCE per chain (from the packed
+// SELL-64 copy below, fully coalesced); rows longer than DMAX stream their tail
+// from L2.  Per step a thread gathers x from LDS and
+// accumulates sequentially in ascending column order with fmaf -- the order of the
+// reference's CPU product.  Vectors ping-pong in LDS, the output slab accumulates in
+// LDS and is written once, coalesced.
+struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
+
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// loads x (fwd) or the upstream-gradient slab (bwd) of a part into LDS, applies the
+// step-0 events (fwd) / forms the Horner start (bwd); returns the event cursor.
+template <bool BWD, int NT>
+__device__ __forceinline__ int chain_prologue(float *xa, float *slab, const float *__restrict__ IN, int64_t first_row,
+                                              int nc, int C, int F, int T, const EvTable &tab)
+{
+    const int tid = threadIdx.x;
+    int p;
+    if (!BWD) {
+        const float *xg = IN + first_row * C;
+        for (int i = tid; i < nc; i += NT) xa[i] = xg[i];
+        int p1 = 0; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
+        for (int i = tid; i < nc; i += NT) {
+            const int c = i % C; const float y = xa[i];
+            for (int k = 0; k < p1; ++k)
+                if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * F, y, tab.e[k].slot, tab.e[k].sign);
+        }
+        p = p1;
+    } else {
+        const float *gg = IN + first_row * C * F;
+        for (int i = tid; i < nc * F; i += NT) slab[i] = gg[i];
+        __syncthreads();
+        int p0 = tab.n; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
+        for (int i = tid; i < nc; i += NT) {
+            const int c = i % C; float y = 0.f;
+            for (int k = p0; k < tab.n; ++k)
+                if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -slab[i * F + tab.e[k].slot] : slab[i * F + tab.e[k].slot];
+            xa[i] = y;
+        }
+        p = p0;
+    }
+    __syncthreads();
+    return p;
+}
+
+template <bool BWD, int NT>
+__device__ __forceinline__ void chain_epilogue(const float *xa, const float *slab, float *__restrict__ RES, int64_t first_row,
+                                               int nc, int C, int F)
+{
+    const int tid = threadIdx.x;
+    if (!BWD) {
+        float *og = RES + first_row * C * F;
+        for (int i = tid; i < nc * F; i += NT) og[i] = slab[i];
+    } else {
+        float *dg = RES + first_row * C;
+        for (int i = tid; i < nc; i += NT) dg[i] = xa[i];
+    }
+}
+
+// events of step `st`: [q0, q1) in the table; moves the cursor (fwd: up, bwd: down)
+template <bool BWD>
+__device__ __forceinline__ void step_range(const EvTable &tab, int st, int &p, int &q0, int &q1)
+{
+    if (!BWD) { q0 = p; q1 = p; while (q1 < tab.n && tab.e[q1].step == st) ++q1; p = q1; }
+    else { q1 = p; q0 = p; while (q0 > 0 && tab.e[q0 - 1].step == st) --q0; p = q0; }
+}
+
+template <bool BWD>
+__device__ __forceinline__ float apply_events(const EvTable &tab, int q0, int q1, int c, float y, float *o)
+{
+    if (BWD) {
+        for (int k = q0; k < q1; ++k)
+            if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -o[tab.e[k].slot] : o[tab.e[k].slot];
+    } else {
+        for (int k = q0; k < q1; ++k)
+            if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(o, y, tab.e[k].slot, tab.e[k].sign);
+    }
+    return y;
+}
+
+// Packed operator for these kernels ("SELL-64": sliced ELLPACK, slice = one wave).
+// Inside each part the rows are sorted by length (descending) and cut into slices
+// of 64; slice s stores its first w_s = min(longest row, dmax) entries slot-major,
+//   CSR   val[(doff_s + d) * 64 + lane]
+//   BSR-3 val[(doff_s + d) * 576 + {0: lane*4 + 0..3 | 256: lane*4 + 0..3 | 512: lane}]
+//         (the 9 floats of a block as two float4 pieces and one scalar piece)
+//   lc[(poff_s + d/2) * 64 + lane] = local column of slot d | local column of slot d+1 << 16
+// so that every load of a wave is one fully coalesced 256-B or 1-KiB access, and
+// the sort makes w_s the length of (nearly) every row of the slice: no idle slots.
+// perm[s*64 + lane] is the row (local to the part) that lane serves, -1 = none.
+struct SellDev {
+    const float *val; const unsigned *lc; const int *perm;
+    const int *slice_doff; const int *slice_poff; const int *part_slice_ptr;
+    int dmax;
+};
+
+template <int DMAX, int NT, bool BWD>
+__global__ void __launch_bounds__(NT)
+k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
+                  const int *__restrict__ part_ptr, SellDev sd, const float *__restrict__ X, float *__restrict__ OUT,
+                  int T, EvTable tab, int F)
+{
+    static_assert(DMAX % 2 == 0, "DMAX must be even (packed column offsets)");
+    extern __shared__ __align__(16) float smem[];
+    const int gs = part_ptr[blockIdx.x], brows = part_ptr[blockIdx.x + 1] - gs;
+    if (brows > NT) return;                       // host guarantees max_part_rows <= NT
+    const int nc = brows * 3;
+    float *xa = smem, *xb = smem + nc, *slab = smem + 2 * nc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
+
+    float b[DMAX * 9];
+    unsigned lc[DMAX / 2];
+    int r = -1, e0 = 0, deg = 0, w = 0;
+    if (wave < ns) {
+        const int s = s0 + wave;
+        const int doff = sd.slice_doff[s], poff = sd.slice_poff[s];
+        w = __builtin_amdgcn_readfirstlane(sd.slice_doff[s + 1] - doff);
+        r = sd.perm[s * 64 + lane];
+        if (r >= 0) { e0 = rowptr[gs + r]; deg = rowptr[gs + r + 1] - e0; }
+        const float *vb = sd.val + (int64_t)doff * 576;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            if (d < w) {                          // wave-uniform
+                const float4 p0 = *reinterpret_cast<const float4 *>(vb + d * 576 + lane * 4);
+                const float4 p1 = *reinterpret_cast<const float4 *>(vb + d * 576 + 256 + lane * 4);
+                const float p2 = vb[d * 576 + 512 + lane];
+                b[9 * d + 0] = p0.x; b[9 * d + 1] = p0.y; b[9 * d + 2] = p0.z; b[9 * d + 3] = p0.w;
+                b[9 * d + 4] = p1.x; b[9 * d + 5] = p1.y; b[9 * d + 6] = p1.z; b[9 * d + 7] = p1.w;
+                b[9 * d + 8] = p2;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) b[9 * d + q] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < DMAX / 2; ++j2) {
+            unsigned v = 0;
+            if (2 * j2 < w) v = sd.lc[(int64_t)(poff + j2) * 64 + lane];
+            lc[j2] = ((v & 0xffffu) * 3u) | (((v >> 16) * 3u) << 16);      // float offsets into the LDS vector
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < DMAX * 9; ++q) b[q] = 0.f;
+#pragma unroll
+        for (int q = 0; q < DMAX / 2; ++q) lc[q] = 0;
+    }
+    const bool own = r >= 0;
+
+    int p = chain_prologue<BWD, NT>(xa, slab, X, gs, nc, 3, F, T, tab);
+    for (int t = 1; t <= T; ++t) {
+        int q0, q1;
+        step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
+        if (own) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                if (d < w) {                      // wave-uniform: slice width
+                    if (d < deg) {
+                        const unsigned off = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
+                        const float *x = xa + off;
+                        const float x0 = x[0], x1 = x[1], x2 = x[2];
+                        a0 = fmaf(b[9 * d + 0], x0, a0); a0 = fmaf(b[9 * d + 1], x1, a0); a0 = fmaf(b[9 * d + 2], x2, a0);
+                        a1 = fmaf(b[9 * d + 3], x0, a1); a1 = fmaf(b[9 * d + 4], x1, a1); a1 = fmaf(b[9 * d + 5], x2, a1);
+                        a2 = fmaf(b[9 * d + 6], x0, a2); a2 = fmaf(b[9 * d + 7], x1, a2); a2 = fmaf(b[9 * d + 8], x2, a2);
+                    }
+                }
+            }
+            for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {   // rows longer than the pack: tail from L2
+                const float *bb = blk + (int64_t)e * 9;
+                const float *x = xa + (col[e] - gs) * 3;
+                const float x0 = x[0], x1 = x[1], x2 = x[2];
+                a0 = fmaf(bb[0], x0, a0); a0 = fmaf(bb[1], x1, a0); a0 = fmaf(bb[2], x2, a0);
+                a1 = fmaf(bb[3], x0, a1); a1 = fmaf(bb[4], x1, a1); a1 = fmaf(bb[5], x2, a1);
+                a2 = fmaf(bb[6], x0, a2); a2 = fmaf(bb[7], x1, a2); a2 = fmaf(bb[8], x2, a2);
+            }
+            float *o = slab + 3 * r * F;
+            xb[3 * r + 0] = apply_events<BWD>(tab, q0, q1, 0, a0, o);
+            xb[3 * r + 1] = apply_events<BWD>(tab, q0, q1, 0, a1, o + F);
+            xb[3 * r + 2] = apply_events<BWD>(tab, q0, q1, 0, a2, o + 2 * F);
+        }
+        __syncthreads();
+        float *sw = xa; xa = xb; xb = sw;
+    }
+    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, nc, 3, F);
+}
+
+template <int C, int DMAX, int NT, bool BWD>
+__global__ void __launch_bounds__(NT)
+k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
+                 const int *__restrict__ part_ptr, SellDev sd, const float *__restrict__ X, float *__restrict__ OUT,
+                 int T, EvTable tab, int F)
+{
+    static_assert(DMAX % 2 == 0, "DMAX must be even (packed column offsets)");
+    extern __shared__ __align__(16) float smem[];
+    const int gs = part_ptr[blockIdx.x], rows = part_ptr[blockIdx.x + 1] - gs;
+    if (rows > NT) return;
+    const int nc = rows * C;
+    float *xa = smem, *xb = smem + nc, *slab = smem + 2 * nc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
+
+    float v[DMAX];
+    unsigned lc[DMAX / 2];
+    int r = -1, e0 = 0, deg = 0, w = 0;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) v[d] = 0.f;
+#pragma unroll
+    for (int q = 0; q < DMAX / 2; ++q) lc[q] = 0;
+    if (wave < ns) {
+        const int s = s0 + wave;
+        const int doff = sd.slice_doff[s], poff = sd.slice_poff[s];
+        w = __builtin_amdgcn_readfirstlane(sd.slice_doff[s + 1] - doff);
+        r = sd.perm[s * 64 + lane];
+        if (r >= 0) { e0 = rowptr[gs + r]; deg = rowptr[gs + r + 1] - e0; }
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+            if (d < w) v[d] = sd.val[(int64_t)(doff + d) * 64 + lane];
+#pragma unroll
+        for (int j2 = 0; j2 < DMAX / 2; ++j2)
+            if (2 * j2 < w) {
+                const unsigned u = sd.lc[(int64_t)(poff + j2) * 64 + lane];
+                lc[j2] = ((u & 0xffffu) * (unsigned)C) | (((u >> 16) * (unsigned)C) << 16);
+            }
+    }
+    const bool own = r >= 0;
+
+    int p = chain_prologue<BWD, NT>(xa, slab, X, gs, nc, C, F, T, tab);
+    for (int t = 1; t <= T; ++t) {
+        int q0, q1;
+        step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
+        if (own) {
+            float acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                if (d < w) {
+                    if (d < deg) {
+                        const unsigned off = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
+                        const float *x = xa + off;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = fmaf(v[d], x[c], acc[c]);
+                    }
+                }
+            }
+            for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {
+                const float vv = val[e];
+                const float *x = xa + (col[e] - gs) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                xb[r * C + c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
+        }
+        __syncthreads();
+        float *sw = xa; xa = xb; xb = sw;
+    }
+    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, nc, C, F);
+}
+
 // ------------------------------------------------------------------ orders 0/1/2 epilogue (ESCGNNModular._scatter)
 __global__ void __launch_bounds__(256)
 k_scatter_orders(const float *__restrict__ x0, const float *__restrict__ W1, int64_t rows, int F, int Wtot,
@@ -574,11 +845,92 @@ static int launch_chain_csr(int C, int G, const int *rp, const int *ci, const fl
     return fail(ESCAT_ERANGE, "C=%d outside [1,%d]", C, ESCAT_MAX_CHANNELS);
 }
 
+// ---- register-resident launchers
+static int chain_path_override()
+{
+    // debugging / A-B aid: ESCAT_CHAIN_PATH = reg | stream | multi forces a path (default: best that fits)
+    const char *e = getenv("ESCAT_CHAIN_PATH");
+    if (!e) return 0;
+    if (!strcmp(e, "reg")) return 1;
+    if (!strcmp(e, "stream")) return 2;
+    if (!strcmp(e, "multi")) return 3;
+    return 0;
+}
+
+#define LAUNCH_SELL(KERN, NTHREADS)                                                                    \
+    do { int rc_ = set_lds(KERN, lds); if (rc_) return rc_;                                            \
+         hipLaunchKernelGGL((KERN), dim3(n_parts), dim3(NTHREADS), lds, st, rp, ci, v, pp, sd, IN, RES, T, tab, F); } while (0)
+
+static int sell_to_dev(const escat_sell *sell, SellDev *sd)
+{
+    if (!sell->val || !sell->lc || !sell->perm || !sell->slice_doff || !sell->slice_poff || !sell->part_slice_ptr)
+        return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
+    if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
+    sd->val = sell->val; sd->lc = sell->lc; sd->perm = sell->perm; sd->slice_doff = sell->slice_doff;
+    sd->slice_poff = sell->slice_poff; sd->part_slice_ptr = sell->part_slice_ptr; sd->dmax = sell->dmax;
+    return ESCAT_OK;
+}
+
+template <int DMAX, bool BWD>
+static int launch_bsr3_sell_d(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
+                              const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    if (NT <= 256) LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 256, BWD>), 256);
+    else           LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 512, BWD>), 512);
+    return ESCAT_OK;
+}
+template <bool BWD>
+static int launch_bsr3_sell(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
+                            size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F,
+                            hipStream_t st)
+{
+    switch (sd.dmax) {
+        case 8:  return launch_bsr3_sell_d<8, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 12: return launch_bsr3_sell_d<12, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 16: return launch_bsr3_sell_d<16, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 22: return launch_bsr3_sell_d<22, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+    }
+    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: BSR-3 packs must use 8, 12, 16 or 22", sd.dmax);
+}
+
+template <int C, int DMAX, bool BWD>
+static int launch_csr_sell_d(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
+                             const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    if (NT <= 256) LAUNCH_SELL((k_chain_csr_sell<C, DMAX, 256, BWD>), 256);
+    else           LAUNCH_SELL((k_chain_csr_sell<C, DMAX, 512, BWD>), 512);
+    return ESCAT_OK;
+}
+template <int C, bool BWD>
+static int launch_csr_sell_c(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
+                             size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F,
+                             hipStream_t st)
+{
+    switch (sd.dmax) {
+        case 8:  return launch_csr_sell_d<C, 8, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 16: return launch_csr_sell_d<C, 16, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 32: return launch_csr_sell_d<C, 32, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+    }
+    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: CSR packs must use 8, 16 or 32", sd.dmax);
+}
+template <bool BWD>
+static int launch_csr_sell(int C, int NT, const int *rp, const int *ci, const float *v, const int *pp,
+                           int n_parts, size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab,
+                           int F, hipStream_t st)
+{
+    switch (C) {
+#define CASE(c) case c: return launch_csr_sell_c<c, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    }
+    return fail(ESCAT_ERANGE, "C=%d outside [1,%d]", C, ESCAT_MAX_CHANNELS);
+}
+
 // shared driver for the scalar chain, forward (BWD=false: IN = X, RES = OUT) and backward (IN = G, RES = dX)
 template <bool BWD>
 static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
                      const float *IN, int C, int T, const escat_event *events, int n_events, int F, float *RES,
-                     const int32_t *part_ptr, int n_parts, int max_part_rows,
+                     const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                      void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_csr(rowptr, col, val, n, nnz); if (rc) return rc;
@@ -591,10 +943,16 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
     hipStream_t st = S(stream);
     const int G = pick_G(n, nnz);
 
-    if (part_ptr && n_parts > 0 && max_part_rows > 0) {
+    const int force = chain_path_override();
+    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force != 3) {
         const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
         if (lds <= LDS_BUDGET) {
-            rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
+            if (max_part_rows <= 512 && sell && force != 2) {
+                SellDev sd;
+                rc = sell_to_dev(sell, &sd); if (rc) return rc;
+                rc = launch_csr_sell<BWD>(C, max_part_rows, rowptr, col, val, part_ptr, n_parts, lds, sd, IN, RES, T, tab, F, st);
+            } else
+                rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_csr");
             return ESCAT_OK;
@@ -638,26 +996,26 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
 
 extern "C" int escat_chain_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
                                    const float *X, int C, int T, const escat_event *events, int n_events, int F, float *OUT,
-                                   const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                   const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                                    void *workspace, size_t workspace_bytes, void *stream)
 {
-    return chain_csr<false>(rowptr, col, val, n, nnz, X, C, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows,
+    return chain_csr<false>(rowptr, col, val, n, nnz, X, C, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows, sell,
                             workspace, workspace_bytes, stream);
 }
 
 extern "C" int escat_chain_csr_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *val_t, int64_t n, int64_t nnz,
                                        const float *G, int C, int T, const escat_event *events, int n_events, int F, float *dX,
-                                       const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                       const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
-    return chain_csr<true>(rowptr_t, col_t, val_t, n, nnz, G, C, T, events, n_events, F, dX, part_ptr, n_parts, max_part_rows,
+    return chain_csr<true>(rowptr_t, col_t, val_t, n, nnz, G, C, T, events, n_events, F, dX, part_ptr, n_parts, max_part_rows, sell,
                            workspace, workspace_bytes, stream);
 }
 
 template <bool BWD>
 static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
                       const float *IN, int T, const escat_event *events, int n_events, int F, float *RES,
-                      const int32_t *part_ptr, int n_parts, int max_part_rows,
+                      const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                       void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_csr(rowptr, col, blk, nb, nnzb); if (rc) return rc;
@@ -671,8 +1029,17 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
     const int g = pick_g(nb, nnzb);
     const int64_t n = 3 * nb;
 
-    if (part_ptr && n_parts > 0 && max_part_rows > 0) {
+    const int force = chain_path_override();
+    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force != 3) {
         const size_t lds = (size_t)max_part_rows * 3 * (2 + F) * sizeof(float);
+        if (lds <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
+            SellDev sd;
+            rc = sell_to_dev(sell, &sd); if (rc) return rc;
+            rc = launch_bsr3_sell<BWD>(max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds, sd, IN, RES, T, tab, F, st);
+            if (rc) return rc;
+            CHECK_LAUNCH("k_chain_bsr3_sell");
+            return ESCAT_OK;
+        }
         if (lds <= LDS_BUDGET) {
 #define GO(gg)                                                                                          \
             rc = set_lds(k_chain_bsr3<gg, BWD>, lds); if (rc) return rc;                                \
@@ -718,19 +1085,19 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
 
 extern "C" int escat_chain_bsr3_f32(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
                                     const float *x, int T, const escat_event *events, int n_events, int F, float *OUT,
-                                    const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                    const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                                     void *workspace, size_t workspace_bytes, void *stream)
 {
-    return chain_bsr3<false>(rowptr, col, blk, nb, nnzb, x, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows,
+    return chain_bsr3<false>(rowptr, col, blk, nb, nnzb, x, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows, sell,
                              workspace, workspace_bytes, stream);
 }
 
 extern "C" int escat_chain_bsr3_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *blk_t, int64_t nb, int64_t nnzb,
                                         const float *G, int T, const escat_event *events, int n_events, int F, float *dx,
-                                        const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                        const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                                         void *workspace, size_t workspace_bytes, void *stream)
 {
-    return chain_bsr3<true>(rowptr_t, col_t, blk_t, nb, nnzb, G, T, events, n_events, F, dx, part_ptr, n_parts, max_part_rows,
+    return chain_bsr3<true>(rowptr_t, col_t, blk_t, nb, nnzb, G, T, events, n_events, F, dx, part_ptr, n_parts, max_part_rows, sell,
                             workspace, workspace_bytes, stream);
 }
 

@@ -69,8 +69,82 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
     return torch.from_numpy(out.astype(np.int32)).to(dev), len(out) - 1, max_rows
 
 
+SELL_MAX_PART_ROWS = 512
+_SELL_DMAX = {1: (8, 16, 32), 9: (8, 12, 16, 22)}     # register capacities the kernels are instantiated for
+
+
+def _cumsum0(t):
+    out = torch.zeros(t.numel() + 1, dtype=torch.int64, device=t.device)
+    torch.cumsum(t, 0, out=out[1:])
+    return out
+
+
+class Sell:
+    """
+    SELL-64 pack of a CSR (val (nnz,)) or BSR-3 (val (nnz,3,3)) operator; layout in
+    include/escat.h (escat_sell).  Built with torch index ops on the operator's device.
+    """
+
+    def __init__(self, form):
+        dev = form.rowptr.device
+        V = 9 if form.val.dim() == 3 else 1
+        caps = _SELL_DMAX[V]
+        self.dmax = next((c for c in caps if c >= form.max_row_nnz), caps[-1])
+        dmax = self.dmax
+        n, nnz = form.n, form.nnz
+        rp = form.rowptr.long()
+        deg = rp[1:] - rp[:-1]
+        pp = form.part_ptr.long()
+        n_parts = form.n_parts
+        part_rows = pp[1:] - pp[:-1]
+        part_of_row = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_rows)
+        dcl = deg.clamp(max=dmax)
+        order = torch.argsort(part_of_row * (dmax + 1) + (dmax - dcl), stable=True)     # rows in slot order
+        part_slices = (part_rows + 63) // 64
+        psp = _cumsum0(part_slices)
+        n_slices = int(psp[-1])
+        slot = psp[part_of_row] * 64 + (torch.arange(n, device=dev) - pp[part_of_row])  # sorted position i -> slot
+        perm = torch.full((n_slices * 64,), -1, dtype=torch.int32, device=dev)
+        perm[slot] = (order - pp[part_of_row]).to(torch.int32)
+        slot_deg = torch.zeros(n_slices * 64, dtype=torch.int64, device=dev)
+        slot_deg[slot] = dcl[order]
+        w = slot_deg.view(n_slices, 64).max(dim=1).values
+        doff, poff = _cumsum0(w), _cumsum0((w + 1) // 2)
+        row_slot = torch.empty(n, dtype=torch.int64, device=dev)
+        row_slot[order] = slot
+        row_of_e = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+        d_of_e = torch.arange(nnz, device=dev) - rp[row_of_e]
+        keep = d_of_e < dmax
+        e_k = torch.nonzero(keep).flatten()
+        r_k, d_k = row_of_e[e_k], d_of_e[e_k]
+        sl = row_slot[r_k]
+        s_k, lane = sl // 64, sl % 64
+        drow = doff[s_k] + d_k
+        total_d, total_p = int(doff[-1]), int(poff[-1])
+        if V == 9:
+            val = torch.zeros(max(total_d, 1) * 576, dtype=torch.float32, device=dev)
+            src = form.val.reshape(nnz, 9)[e_k]
+            for q in range(9):
+                dst = drow * 576 + (q // 4) * 256 + (lane * 4 + q % 4 if q < 8 else lane)
+                val[dst] = src[:, q]
+        else:
+            val = torch.zeros(max(total_d, 1) * 64, dtype=torch.float32, device=dev)
+            val[drow * 64 + lane] = form.val[e_k]
+        lcl = form.col.long()[e_k] - pp[part_of_row[r_k]]
+        lc = torch.zeros(max(total_p, 1) * 64, dtype=torch.int64, device=dev)
+        lc.index_add_(0, (poff[s_k] + d_k // 2) * 64 + lane, lcl << (16 * (d_k % 2)))
+        self.val = val
+        self.lc = lc.to(torch.int32)          # bit pattern of the packed uint32 pairs (values < 2^26 here)
+        self.perm = perm
+        self.slice_doff = doff.to(torch.int32)
+        self.slice_poff = poff.to(torch.int32)
+        self.part_slice_ptr = psp.to(torch.int32)
+        self.n_slices = n_slices
+        self.pad_ratio = float(total_d * 64) / max(float(dcl.sum()), 1.0)
+
+
 class _Csr:
-    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows")
+    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "max_row_nnz", "_sell")
 
     def __init__(self, rowptr, col, val, n, parts=None):
         self.rowptr, self.col, self.val, self.n = rowptr, col, val, n
@@ -78,6 +152,14 @@ class _Csr:
         if parts is None:
             parts = _closed_row_ranges(rowptr, col, n, PART_TARGET_ROWS)
         self.part_ptr, self.n_parts, self.max_part_rows = parts
+        self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) if n > 0 else 0
+        self._sell = None
+
+    def sell(self):
+        """packed SELL-64 copy for the register-resident kernels (None if the parts are too large)."""
+        if self._sell is None and 0 < self.max_part_rows <= SELL_MAX_PART_ROWS and self.nnz > 0:
+            self._sell = Sell(self)
+        return self._sell
 
 
 class ScatterOperator:

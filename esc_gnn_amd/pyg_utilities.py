@@ -9,6 +9,7 @@ There is no CPU path: tensors must live on the GPU and the HIP library must be
 built, otherwise this raises.
 """
 import ctypes
+import os
 from typing import Optional
 import torch
 
@@ -46,23 +47,32 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
     rows_per = 3 if use_bsr else 1
     out = torch.empty((n, C) if backward else (n, C, F), dtype=torch.float32, device=dev)
     lds = form.max_part_rows * rows_per * C * (2 + F) * 4
-    fused = form.n_parts > 0 and lds <= LDS_BUDGET
+    fused = form.n_parts > 0 and lds <= LDS_BUDGET and os.environ.get("ESCAT_CHAIN_PATH") != "multi"
     ws = None
     if not fused and T > 0:
         ws = torch.empty(lib.escat_chain_workspace_bytes(n, C) // 4, dtype=torch.float32, device=dev)
     ws_bytes = ws.numel() * 4 if ws is not None else 0
+    sell = form.sell() if fused else None
+    if sell is not None and (form.max_part_rows * rows_per * C > 0xffff or os.environ.get("ESCAT_CHAIN_PATH") == "stream"):
+        sell = None
+    sell_ref = ctypes.c_void_p(0)
+    if sell is not None:
+        sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.perm.data_ptr(),
+                                     sell.slice_doff.data_ptr(), sell.slice_poff.data_ptr(),
+                                     sell.part_slice_ptr.data_ptr(), sell.dmax, sell.n_slices)
+        sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)
         if use_bsr:
             fn = lib.escat_chain_bsr3_bwd_f32 if backward else lib.escat_chain_bsr3_f32
             rc = fn(_ptr(form.rowptr), _ptr(form.col), _ptr(form.val), form.n, form.nnz, _ptr(inp), T,
                     ctypes.cast(ev, ctypes.c_void_p), len(plan_events), F, _ptr(out),
-                    _ptr(form.part_ptr), form.n_parts, form.max_part_rows, _ptr(ws), ws_bytes, st)
+                    _ptr(form.part_ptr), form.n_parts, form.max_part_rows, sell_ref, _ptr(ws), ws_bytes, st)
         else:
             fn = lib.escat_chain_csr_bwd_f32 if backward else lib.escat_chain_csr_f32
             rc = fn(_ptr(form.rowptr), _ptr(form.col), _ptr(form.val), form.n, form.nnz, _ptr(inp), C, T,
                     ctypes.cast(ev, ctypes.c_void_p), len(plan_events), F, _ptr(out),
-                    _ptr(form.part_ptr), form.n_parts, form.max_part_rows, _ptr(ws), ws_bytes, st)
+                    _ptr(form.part_ptr), form.n_parts, form.max_part_rows, sell_ref, _ptr(ws), ws_bytes, st)
     _lib.check(rc, fn.__name__ if hasattr(fn, "__name__") else "escat chain")
     return out
 

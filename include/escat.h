@@ -58,6 +58,32 @@ extern "C" {
 
 typedef struct { int32_t step, slot, sign, chan; } escat_event;
 
+/* Packed "SELL-64" copy of a CSR / BSR-3 operator for the register-resident
+ * chain kernels (all members are device pointers; the struct itself lives on
+ * the host).  Inside each part rows are sorted by length, descending, and cut
+ * into slices of 64 rows (one wave); slice s keeps the first
+ * w_s = min(longest row of the slice, dmax) entries of each row, slot-major:
+ *   CSR   val[(doff_s + d)*64 + lane]
+ *   BSR-3 val[(doff_s + d)*576 + {lane*4+0..3 | 256+lane*4+0..3 | 512+lane}]
+ *         = block floats 0-3 | 4-7 | 8
+ *   lc[(poff_s + d/2)*64 + lane] = local col of slot d | local col of slot d+1 << 16
+ *         (local = column - first row of the part; 0 where the row is shorter)
+ * with doff_s = slice_doff[s], poff_s = slice_poff[s] (prefix sums of w_s and
+ * ceil(w_s/2)), perm[s*64 + lane] = local row served by that lane (-1: none),
+ * part_slice_ptr[p] = first slice of part p.  Entries beyond dmax stay in the
+ * CSR / BSR-3 arrays and are streamed.  dmax: 8/16/32 (CSR), 8/12/16/22 (BSR-3).
+ * esc_gnn_amd/operators.py builds it (torch index ops, once per operator). */
+typedef struct {
+    const float    *val;
+    const uint32_t *lc;
+    const int32_t  *perm;
+    const int32_t  *slice_doff;
+    const int32_t  *slice_poff;
+    const int32_t  *part_slice_ptr;
+    int32_t         dmax;
+    int32_t         n_slices;
+} escat_sell;
+
 /* last error message of the calling thread ("" if none). */
 const char *escat_last_error(void);
 /* ABI version, bumped when a signature changes. */
@@ -91,11 +117,15 @@ size_t escat_chain_workspace_bytes(int64_t n_rows, int C);
  *                one workgroup with the vectors resident in LDS for all T
  *                steps; otherwise T step kernels run over the whole operator
  *                using `workspace`.
+ *   sell         host pointer to a packed copy of the operator (escat_sell
+ *                below) or NULL.  With it, and parts of <= 512 rows, one thread
+ *                owns one row and keeps the row's entries in registers for all
+ *                T steps: the operator is read from HBM once per chain.
  */
 int escat_chain_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                         int64_t n, int64_t nnz, const float *X, int C, int T,
                         const escat_event *events, int n_events, int F, float *OUT,
-                        const int32_t *part_ptr, int n_parts, int max_part_rows,
+                        const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the above w.r.t. X (what autograd of the reference's chain
@@ -105,7 +135,7 @@ int escat_chain_csr_f32(const int32_t *rowptr, const int32_t *col, const float *
 int escat_chain_csr_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *val_t,
                             int64_t n, int64_t nnz, const float *G, int C, int T,
                             const escat_event *events, int n_events, int F, float *dX,
-                            const int32_t *part_ptr, int n_parts, int max_part_rows,
+                            const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* Forward filter bank, vector track: x is the (3*nb,) flattening of (nb, 3)
@@ -115,7 +145,7 @@ int escat_chain_csr_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const
 int escat_chain_bsr3_f32(const int32_t *rowptr, const int32_t *col, const float *blk,
                          int64_t nb, int64_t nnzb, const float *x, int T,
                          const escat_event *events, int n_events, int F, float *OUT,
-                         const int32_t *part_ptr, int n_parts, int max_part_rows,
+                         const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the vector-track bank; takes Q^T in BSR-3 (block (j,i) of Q^T is
@@ -123,7 +153,7 @@ int escat_chain_bsr3_f32(const int32_t *rowptr, const int32_t *col, const float 
 int escat_chain_bsr3_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, const float *blk_t,
                              int64_t nb, int64_t nnzb, const float *G, int T,
                              const escat_event *events, int n_events, int F, float *dx,
-                             const int32_t *part_ptr, int n_parts, int max_part_rows,
+                             const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                              void *workspace, size_t workspace_bytes, void *stream);
 
 /* Orders 0/1/2 of ESCGNNModular._scatter (models/escgnn_modular.py:333-341,

@@ -206,22 +206,62 @@ def test_vs_c_oracle_seeded(oracle_lib, B, n, k, J):
     _close(xvg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T), rtol=2e-5)
 
 
-def test_fused_and_multilaunch_paths_agree():
-    """same operator with and without row ranges -> LDS-fused kernel vs T step kernels."""
-    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic
+def test_all_three_chain_paths_agree(monkeypatch):
+    """register-resident (one thread per row), LDS-fused streaming (lane groups) and multi-launch step kernels
+    on the same operator, forward and backward, against each other and the C oracle."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
     dev = _dev()
     b = synthetic.ellipsoid_batch(8, 300, 10, seed=9)
     t = lambda a: torch.from_numpy(a).to(dev)
-    none = (torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
-    x = torch.randn(b["N"], 3, device=dev)
-    xv = t(b["pos"]).reshape(-1, 1)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    assert opP.csr().max_part_rows == 300 and opQ.bsr3().max_row_nnz >= 11
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b["N"], 3, generator=g)
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
     for kw in (dict(J=4), dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16]))):
-        Wf = get_Batch_Wjxs(x, ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"]), **kw)
-        Wm = get_Batch_Wjxs(x, ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"], parts=none), **kw)
-        assert (Wf - Wm).abs().max() <= 1e-6 * Wf.abs().max()    # same lane mapping and summation order
-        Qf = get_Batch_Wjxs(xv, ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"]), **kw)
-        Qm = get_Batch_Wjxs(xv, ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"], parts=none), **kw)
-        assert (Qf - Qm).abs().max() <= 1e-6 * Qf.abs().max()
+        plan = plan_chain(**kw)
+        ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+        gP = torch.randn(b["N"], 3, plan.F, generator=g)
+        gQ = torch.randn(3 * b["N"], 1, plan.F, generator=g)
+        refP = co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F)
+        refQ = co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F)
+        refgP = co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T)
+        refgQ = co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T)
+        outs = {}
+        for path in ("reg", "stream", "multi"):
+            monkeypatch.setenv("ESCAT_CHAIN_PATH", path)
+            xg = x.to(dev).requires_grad_(True)
+            W = get_Batch_Wjxs(xg, opP, **kw)
+            W.backward(gP.to(dev))
+            xq = xv.to(dev).requires_grad_(True)
+            Wq = get_Batch_Wjxs(xq, opQ, **kw)
+            Wq.backward(gQ.to(dev))
+            _close(W, refP); _close(Wq, refQ)
+            _close(xg.grad, refgP, rtol=2e-5); _close(xq.grad, refgQ, rtol=2e-5)
+            outs[path] = (W.detach(), Wq.detach())
+        # lane-group paths share lane mapping and summation order
+        assert (outs["stream"][0] - outs["multi"][0]).abs().max() <= 1e-6 * outs["multi"][0].abs().max()
+        assert (outs["stream"][1] - outs["multi"][1]).abs().max() <= 1e-6 * outs["multi"][1].abs().max()
+    monkeypatch.delenv("ESCAT_CHAIN_PATH")
+
+
+def test_register_path_long_rows_and_small_parts():
+    """rows longer than the register capacity (DMAX) take the streamed tail; parts of many tiny graphs."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(2, 120, 30, seed=5)            # k=30: rows of 31..60 entries > DMAX=22/32
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    assert opQ.bsr3().max_row_nnz > 32
+    plan = plan_chain(J=3)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    x = torch.randn(b["N"], 5, generator=torch.Generator().manual_seed(2))
+    _close(get_Batch_Wjxs(x.to(dev), opP, J=3), co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F))
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    _close(get_Batch_Wjxs(xv.to(dev), opQ, J=3),
+           co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F))
 
 
 def test_properties_at_benchmark_size():
