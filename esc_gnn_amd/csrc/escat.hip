@@ -419,20 +419,26 @@ __device__ __forceinline__ int wave_max_i(int v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+// LDS vectors of these kernels are padded: row r, channel c lives at r*CP + c with
+// CP = C rounded up to 1/2/4/8 floats, so that a gather is one aligned ds_read_b32/
+// b64/b128; one extra all-zero row at index `rows` is the target of padded slots.
+//
 // loads x (fwd) or the upstream-gradient slab (bwd) of a part into LDS, applies the
 // step-0 events (fwd) / forms the Horner start (bwd); returns the event cursor.
 template <bool BWD, int NT>
-__device__ __forceinline__ int chain_prologue(float *xa, float *slab, const float *__restrict__ IN, int64_t first_row,
-                                              int nc, int C, int F, int T, const EvTable &tab)
+__device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab, const float *__restrict__ IN,
+                                              int64_t first_row, int rows, int C, int CP, int F, int T, const EvTable &tab)
 {
     const int tid = threadIdx.x;
+    const int nc = rows * C;
     int p;
+    if (tid < CP) { xa[rows * CP + tid] = 0.f; xb[rows * CP + tid] = 0.f; }
     if (!BWD) {
         const float *xg = IN + first_row * C;
-        for (int i = tid; i < nc; i += NT) xa[i] = xg[i];
         int p1 = 0; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
         for (int i = tid; i < nc; i += NT) {
-            const int c = i % C; const float y = xa[i];
+            const int c = i % C; const float y = xg[i];
+            xa[(i / C) * CP + c] = y;
             for (int k = 0; k < p1; ++k)
                 if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * F, y, tab.e[k].slot, tab.e[k].sign);
         }
@@ -446,7 +452,7 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *slab, const floa
             const int c = i % C; float y = 0.f;
             for (int k = p0; k < tab.n; ++k)
                 if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -slab[i * F + tab.e[k].slot] : slab[i * F + tab.e[k].slot];
-            xa[i] = y;
+            xa[(i / C) * CP + c] = y;
         }
         p = p0;
     }
@@ -456,15 +462,16 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *slab, const floa
 
 template <bool BWD, int NT>
 __device__ __forceinline__ void chain_epilogue(const float *xa, const float *slab, float *__restrict__ RES, int64_t first_row,
-                                               int nc, int C, int F)
+                                               int rows, int C, int CP, int F)
 {
     const int tid = threadIdx.x;
+    const int nc = rows * C;
     if (!BWD) {
         float *og = RES + first_row * C * F;
         for (int i = tid; i < nc * F; i += NT) og[i] = slab[i];
     } else {
         float *dg = RES + first_row * C;
-        for (int i = tid; i < nc; i += NT) dg[i] = xa[i];
+        for (int i = tid; i < nc; i += NT) dg[i] = xa[(i / C) * CP + i % C];
     }
 }
 
@@ -497,13 +504,17 @@ __device__ __forceinline__ float apply_events(const EvTable &tab, int q0, int q1
 //         (the 9 floats of a block as two float4 pieces and one scalar piece)
 //   lc[(poff_s + d/2) * 64 + lane] = local column of slot d | local column of slot d+1 << 16
 // so that every load of a wave is one fully coalesced 256-B or 1-KiB access, and
-// the sort makes w_s the length of (nearly) every row of the slice: no idle slots.
+// the sort makes w_s the length of (nearly) every row of the slice: few idle slots.
+// Slots past a row's end hold value 0 and local column = rows of the part (the
+// all-zero LDS row), so the step loop needs no per-lane predication.
 // perm[s*64 + lane] is the row (local to the part) that lane serves, -1 = none.
 struct SellDev {
     const float *val; const unsigned *lc; const int *perm;
     const int *slice_doff; const int *slice_poff; const int *part_slice_ptr;
     int dmax;
 };
+
+#define SLOT_GROUP 4      // slots issued together: their LDS gathers are in flight at once
 
 template <int DMAX, int NT, bool BWD>
 __global__ void __launch_bounds__(NT)
@@ -515,14 +526,19 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
     extern __shared__ __align__(16) float smem[];
     const int gs = part_ptr[blockIdx.x], brows = part_ptr[blockIdx.x + 1] - gs;
     if (brows > NT) return;                       // host guarantees max_part_rows <= NT
-    const int nc = brows * 3;
-    float *xa = smem, *xb = smem + nc, *slab = smem + 2 * nc;
+    const int nv = (brows + 1) * 4;               // padded vector: float4 per node + the zero node
+    float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
+    const unsigned zoff = (unsigned)brows * 4u;
 
     float b[DMAX * 9];
     unsigned lc[DMAX / 2];
     int r = -1, e0 = 0, deg = 0, w = 0;
+#pragma unroll
+    for (int q = 0; q < DMAX * 9; ++q) b[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < DMAX / 2; ++q) lc[q] = zoff | (zoff << 16);
     if (wave < ns) {
         const int s = s0 + wave;
         const int doff = sd.slice_doff[s], poff = sd.slice_poff[s];
@@ -539,77 +555,91 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
                 b[9 * d + 0] = p0.x; b[9 * d + 1] = p0.y; b[9 * d + 2] = p0.z; b[9 * d + 3] = p0.w;
                 b[9 * d + 4] = p1.x; b[9 * d + 5] = p1.y; b[9 * d + 6] = p1.z; b[9 * d + 7] = p1.w;
                 b[9 * d + 8] = p2;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) b[9 * d + q] = 0.f;
             }
         }
 #pragma unroll
         for (int j2 = 0; j2 < DMAX / 2; ++j2) {
-            unsigned v = 0;
-            if (2 * j2 < w) v = sd.lc[(int64_t)(poff + j2) * 64 + lane];
-            lc[j2] = ((v & 0xffffu) * 3u) | (((v >> 16) * 3u) << 16);      // float offsets into the LDS vector
+            if (2 * j2 < w) {
+                const unsigned v = sd.lc[(int64_t)(poff + j2) * 64 + lane];
+                lc[j2] = ((v & 0xffffu) * 4u) | (((v >> 16) * 4u) << 16);      // float offsets into the LDS vector
+            }
         }
-    } else {
-#pragma unroll
-        for (int q = 0; q < DMAX * 9; ++q) b[q] = 0.f;
-#pragma unroll
-        for (int q = 0; q < DMAX / 2; ++q) lc[q] = 0;
     }
     const bool own = r >= 0;
 
-    int p = chain_prologue<BWD, NT>(xa, slab, X, gs, nc, 3, F, T, tab);
+    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, brows, 3, 4, F, T, tab);
     for (int t = 1; t <= T; ++t) {
         int q0, q1;
         step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
-        if (own) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) {
-                if (d < w) {                      // wave-uniform: slice width
-                    if (d < deg) {
+        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
+            if (d0 < w) {                         // wave-uniform: slice width, in groups
+                float4 xv[SLOT_GROUP];
+#pragma unroll
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) {
                         const unsigned off = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
-                        const float *x = xa + off;
-                        const float x0 = x[0], x1 = x[1], x2 = x[2];
+                        xv[g] = *reinterpret_cast<const float4 *>(xa + off);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) {
+                        const float x0 = xv[g].x, x1 = xv[g].y, x2 = xv[g].z;
                         a0 = fmaf(b[9 * d + 0], x0, a0); a0 = fmaf(b[9 * d + 1], x1, a0); a0 = fmaf(b[9 * d + 2], x2, a0);
                         a1 = fmaf(b[9 * d + 3], x0, a1); a1 = fmaf(b[9 * d + 4], x1, a1); a1 = fmaf(b[9 * d + 5], x2, a1);
                         a2 = fmaf(b[9 * d + 6], x0, a2); a2 = fmaf(b[9 * d + 7], x1, a2); a2 = fmaf(b[9 * d + 8], x2, a2);
                     }
                 }
             }
+        }
+        if (own) {
             for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {   // rows longer than the pack: tail from L2
                 const float *bb = blk + (int64_t)e * 9;
-                const float *x = xa + (col[e] - gs) * 3;
+                const float *x = xa + (col[e] - gs) * 4;
                 const float x0 = x[0], x1 = x[1], x2 = x[2];
                 a0 = fmaf(bb[0], x0, a0); a0 = fmaf(bb[1], x1, a0); a0 = fmaf(bb[2], x2, a0);
                 a1 = fmaf(bb[3], x0, a1); a1 = fmaf(bb[4], x1, a1); a1 = fmaf(bb[5], x2, a1);
                 a2 = fmaf(bb[6], x0, a2); a2 = fmaf(bb[7], x1, a2); a2 = fmaf(bb[8], x2, a2);
             }
             float *o = slab + 3 * r * F;
-            xb[3 * r + 0] = apply_events<BWD>(tab, q0, q1, 0, a0, o);
-            xb[3 * r + 1] = apply_events<BWD>(tab, q0, q1, 0, a1, o + F);
-            xb[3 * r + 2] = apply_events<BWD>(tab, q0, q1, 0, a2, o + 2 * F);
+            xb[4 * r + 0] = apply_events<BWD>(tab, q0, q1, 0, a0, o);
+            xb[4 * r + 1] = apply_events<BWD>(tab, q0, q1, 0, a1, o + F);
+            xb[4 * r + 2] = apply_events<BWD>(tab, q0, q1, 0, a2, o + 2 * F);
         }
         __syncthreads();
         float *sw = xa; xa = xb; xb = sw;
     }
-    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, nc, 3, F);
+    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, brows, 3, 4, F);
 }
 
+template <int CP> struct XVec;
+template <> struct XVec<1> { float v[1]; __device__ __forceinline__ void load(const float *p) { v[0] = p[0]; } };
+template <> struct XVec<2> { float v[2]; __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; } };
+template <> struct XVec<4> { float v[4]; __device__ __forceinline__ void load(const float *p) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; } };
+template <> struct XVec<8> { float v[8]; __device__ __forceinline__ void load(const float *p) {
+    const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 4);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; } };
+
 template <int C, int DMAX, int NT, bool BWD>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 4)          // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
 k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
                  const int *__restrict__ part_ptr, SellDev sd, const float *__restrict__ X, float *__restrict__ OUT,
                  int T, EvTable tab, int F)
 {
     static_assert(DMAX % 2 == 0, "DMAX must be even (packed column offsets)");
+    constexpr int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
     extern __shared__ __align__(16) float smem[];
     const int gs = part_ptr[blockIdx.x], rows = part_ptr[blockIdx.x + 1] - gs;
     if (rows > NT) return;
-    const int nc = rows * C;
-    float *xa = smem, *xb = smem + nc, *slab = smem + 2 * nc;
+    const int nv = ((rows + 1) * CP + 3) & ~3;
+    float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
+    const unsigned zoff = (unsigned)rows * (unsigned)CP;
 
     float v[DMAX];
     unsigned lc[DMAX / 2];
@@ -617,7 +647,7 @@ k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, co
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) v[d] = 0.f;
 #pragma unroll
-    for (int q = 0; q < DMAX / 2; ++q) lc[q] = 0;
+    for (int q = 0; q < DMAX / 2; ++q) lc[q] = zoff | (zoff << 16);
     if (wave < ns) {
         const int s = s0 + wave;
         const int doff = sd.slice_doff[s], poff = sd.slice_poff[s];
@@ -631,44 +661,52 @@ k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, co
         for (int j2 = 0; j2 < DMAX / 2; ++j2)
             if (2 * j2 < w) {
                 const unsigned u = sd.lc[(int64_t)(poff + j2) * 64 + lane];
-                lc[j2] = ((u & 0xffffu) * (unsigned)C) | (((u >> 16) * (unsigned)C) << 16);
+                lc[j2] = ((u & 0xffffu) * (unsigned)CP) | (((u >> 16) * (unsigned)CP) << 16);
             }
     }
     const bool own = r >= 0;
 
-    int p = chain_prologue<BWD, NT>(xa, slab, X, gs, nc, C, F, T, tab);
+    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, rows, C, CP, F, T, tab);
     for (int t = 1; t <= T; ++t) {
         int q0, q1;
         step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
-        if (own) {
-            float acc[C];
+        float acc[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) {
-                if (d < w) {
-                    if (d < deg) {
-                        const unsigned off = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
-                        const float *x = xa + off;
+        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
+            if (d0 < w) {
+                XVec<CP> xv[SLOT_GROUP];
 #pragma unroll
-                        for (int c = 0; c < C; ++c) acc[c] = fmaf(v[d], x[c], acc[c]);
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) xv[g].load(xa + ((d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu)));
+                }
+#pragma unroll
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = fmaf(v[d], xv[g].v[c], acc[c]);
                     }
                 }
             }
+        }
+        if (own) {
             for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {
                 const float vv = val[e];
-                const float *x = xa + (col[e] - gs) * C;
+                const float *x = xa + (col[e] - gs) * CP;
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
             }
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                xb[r * C + c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
+                xb[r * CP + c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
         }
         __syncthreads();
         float *sw = xa; xa = xb; xb = sw;
     }
-    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, nc, C, F);
+    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, rows, C, CP, F);
 }
 
 // ------------------------------------------------------------------ orders 0/1/2 epilogue (ESCGNNModular._scatter)
@@ -909,9 +947,10 @@ static int launch_csr_sell_c(int NT, const int *rp, const int *ci, const float *
     switch (sd.dmax) {
         case 8:  return launch_csr_sell_d<C, 8, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
         case 16: return launch_csr_sell_d<C, 16, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 24: return launch_csr_sell_d<C, 24, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
         case 32: return launch_csr_sell_d<C, 32, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
     }
-    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: CSR packs must use 8, 16 or 32", sd.dmax);
+    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: CSR packs must use 8, 16, 24 or 32", sd.dmax);
 }
 template <bool BWD>
 static int launch_csr_sell(int C, int NT, const int *rp, const int *ci, const float *v, const int *pp,
@@ -947,10 +986,13 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
     if (part_ptr && n_parts > 0 && max_part_rows > 0 && force != 3) {
         const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
         if (lds <= LDS_BUDGET) {
-            if (max_part_rows <= 512 && sell && force != 2) {
+            const int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
+            const size_t nv = (((size_t)max_part_rows + 1) * CP + 3) & ~(size_t)3;
+            const size_t lds_s = (2 * nv + (size_t)max_part_rows * C * F) * sizeof(float);
+            if (max_part_rows <= 512 && sell && force != 2 && lds_s <= LDS_BUDGET) {
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
-                rc = launch_csr_sell<BWD>(C, max_part_rows, rowptr, col, val, part_ptr, n_parts, lds, sd, IN, RES, T, tab, F, st);
+                rc = launch_csr_sell<BWD>(C, max_part_rows, rowptr, col, val, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
             } else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
             if (rc) return rc;
@@ -1032,10 +1074,11 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
     const int force = chain_path_override();
     if (part_ptr && n_parts > 0 && max_part_rows > 0 && force != 3) {
         const size_t lds = (size_t)max_part_rows * 3 * (2 + F) * sizeof(float);
-        if (lds <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
+        const size_t lds_s = (2 * ((size_t)max_part_rows + 1) * 4 + (size_t)max_part_rows * 3 * F) * sizeof(float);
+        if (lds <= LDS_BUDGET && lds_s <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
-            rc = launch_bsr3_sell<BWD>(max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds, sd, IN, RES, T, tab, F, st);
+            rc = launch_bsr3_sell<BWD>(max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_bsr3_sell");
             return ESCAT_OK;

@@ -70,7 +70,7 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
 
 
 SELL_MAX_PART_ROWS = 512
-_SELL_DMAX = {1: (8, 16, 32), 9: (8, 12, 16, 22)}     # register capacities the kernels are instantiated for
+_SELL_DMAX = {1: (8, 16, 24, 32), 9: (8, 12, 16, 22)}     # register capacities the kernels are instantiated for
 
 
 def _cumsum0(t):
@@ -130,9 +130,25 @@ class Sell:
         else:
             val = torch.zeros(max(total_d, 1) * 64, dtype=torch.float32, device=dev)
             val[drow * 64 + lane] = form.val[e_k]
-        lcl = form.col.long()[e_k] - pp[part_of_row[r_k]]
-        lc = torch.zeros(max(total_p, 1) * 64, dtype=torch.int64, device=dev)
-        lc.index_add_(0, (poff[s_k] + d_k // 2) * 64 + lane, lcl << (16 * (d_k % 2)))
+        # local columns, one int per (slice, slot, lane); slots past a row's end point at the part's all-zero LDS row
+        slice_part = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_slices)
+        zc = part_rows[slice_part]                                                        # per slice
+        slice_of_drow = torch.repeat_interleave(torch.arange(n_slices, device=dev), w)
+        lcu = zc[slice_of_drow].repeat_interleave(64)                                     # (total_d*64,)
+        lcu[drow * 64 + lane] = form.col.long()[e_k] - pp[part_of_row[r_k]]
+        npair = (w + 1) // 2
+        slice_of_pair = torch.repeat_interleave(torch.arange(n_slices, device=dev), npair)
+        j2 = torch.arange(total_p, device=dev) - poff[slice_of_pair]
+        d_lo = doff[slice_of_pair] + 2 * j2
+        has_hi = (2 * j2 + 1) < w[slice_of_pair]
+        lanes = torch.arange(64, device=dev)
+        lo = lcu[(d_lo[:, None] * 64 + lanes[None, :]).reshape(-1)].view(-1, 64) if total_p else lcu.view(0, 64)
+        d_hi = torch.where(has_hi, d_lo + 1, d_lo)
+        hi = lcu[(d_hi[:, None] * 64 + lanes[None, :]).reshape(-1)].view(-1, 64) if total_p else lo
+        hi = torch.where(has_hi[:, None], hi, zc[slice_of_pair][:, None].expand(-1, 64))
+        lc = (lo | (hi << 16)).reshape(-1)
+        if total_p == 0:
+            lc = torch.zeros(64, dtype=torch.int64, device=dev)
         self.val = val
         self.lc = lc.to(torch.int32)          # bit pattern of the packed uint32 pairs (values < 2^26 here)
         self.perm = perm

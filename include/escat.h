@@ -71,7 +71,7 @@ typedef struct { int32_t step, slot, sign, chan; } escat_event;
  * with doff_s = slice_doff[s], poff_s = slice_poff[s] (prefix sums of w_s and
  * ceil(w_s/2)), perm[s*64 + lane] = local row served by that lane (-1: none),
  * part_slice_ptr[p] = first slice of part p.  Entries beyond dmax stay in the
- * CSR / BSR-3 arrays and are streamed.  dmax: 8/16/32 (CSR), 8/12/16/22 (BSR-3).
+ * CSR / BSR-3 arrays and are streamed.  dmax: 8/16/24/32 (CSR), 8/12/16/22 (BSR-3).
  * esc_gnn_amd/operators.py builds it (torch index ops, once per operator). */
 typedef struct {
     const float    *val;

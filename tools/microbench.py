@@ -10,6 +10,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=500)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--Jmax", type=int, default=4)
+    ap.add_argument("--Jmin", type=int, default=0)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--gen-workers", type=int, default=min(16, os.cpu_count()))
     args = ap.parse_args()
@@ -25,7 +26,7 @@ def main():
     xs = t(b["pos"]).clone().requires_grad_(True)
     xv = t(b["pos"]).reshape(-1, 1).clone().requires_grad_(True)
     res = {"max_row_nnz": opQ.bsr3().max_row_nnz, "nnz": b["nnz"], "N": b["N"], "path": os.environ.get("ESCAT_CHAIN_PATH", "auto")}
-    for J in range(0, args.Jmax + 1):
+    for J in range(args.Jmin, args.Jmax + 1):
         plan = plan_chain(J=J)
         for name, x, op in (("P", xs, opP), ("Q", xv, opQ)):
             g = torch.randn(x.shape[0], x.shape[1], plan.F, device=dev)
