@@ -173,10 +173,8 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from esc_gnn_amd.dist_utils import max_over_ranks
+    dt = max_over_ranks(dt, dev)
 
     if rank == 0:
         per = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i, nm in enumerate(names)}

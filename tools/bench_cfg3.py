@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""BASELINE cfg3: one large point cloud (default 2M nodes, kNN k=16), vector-track Q chain J=6 on one GPU.
+The graph does not fit LDS, so this exercises the multi-launch step kernels (operator streamed from HBM each step).
+Prints one JSON line: ms per chain, algorithmic GB/s (T(4(N+1)+40nnz)+12N+12NF) and per-step figures."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=2_000_000)
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--J", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--check", action="store_true", help="telescoping-sum property check on the result")
+    args = ap.parse_args()
+    from esc_gnn_amd import synthetic
+    t0 = time.time()
+    b = synthetic.single_cloud(args.n, args.k, workers=min(16, os.cpu_count()))
+    gen_s = time.time() - t0
+    import torch
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    op = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"], validate=True,
+                                   parts=(torch.zeros(1, dtype=torch.int32, device=dev), 0, 0))
+    plan = plan_chain(J=args.J)
+    xv = t(b["pos"]).reshape(-1, 1).clone().requires_grad_(args.bwd)
+    if args.bwd:
+        op.bsr3_t()
+    N, nnz, T, F = b["N"], b["nnz"], plan.T, plan.F
+    g = torch.randn(3 * N, 1, F, device=dev) if args.bwd else None
+    tf = tb = 0.0
+    for r in range(args.reps + 1):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        W = get_Batch_Wjxs(xv, op, J=args.J)
+        e[1].record()
+        if args.bwd:
+            xv.grad = None
+            W.backward(g)
+        e[2].record()
+        torch.cuda.synchronize()
+        if r >= 1:
+            tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
+    tf /= args.reps; tb /= args.reps
+    alg = T * (4 * (N + 1) + 40 * nnz) + 12 * N + 12 * N * F
+    out = {"workload": f"cfg3: single cloud n={N}, k={args.k}, Q BSR-3 chain J={args.J} (T={T}, F={F})", "nnz_blocks": nnz,
+           "mean_row_blocks": nnz / N, "fwd_ms": tf, "fwd_alg_GBs": alg / (tf * 1e-3) / 1e9, "fwd_ms_per_step": tf / T,
+           "frac_of_8TBs": alg / (tf * 1e-3) / 1e9 / 8000.0, "gen_s": gen_s}
+    if args.bwd:
+        out.update({"bwd_ms": tb, "bwd_alg_GBs": alg / (tb * 1e-3) / 1e9})
+    if args.check:
+        out["telescoping_max_abs_err"] = float((W.detach().sum(-1).reshape(-1) - xv.detach().reshape(-1)).abs().max())
+    print(json.dumps(out))
+
+if __name__ == "__main__":
+    main()
