@@ -43,6 +43,10 @@ SIGNATURES = {
     "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_scatter_orders_f32": (ci, [vp, vp, i64, ci, ci, vp, vp]),
     "escat_scatter_orders_bwd_f32": (ci, [vp, vp, i64, ci, ci, vp, vp, vp]),
+    "escat_build_workspace_bytes": (sz, [i64, ci, ci]),
+    "escat_build_knn_P": (ci, [vp, vp, ci, i64, ci, ci, vp, vp, vp, i64, vp, vp, sz, vp]),
+    "escat_build_frames": (ci, [vp, vp, vp, i64, ci, ctypes.c_float, ci, ctypes.c_float, ci, ci, ci, vp, vp, vp]),
+    "escat_build_Q_bsr3": (ci, [vp, vp, vp, vp, i64, ci, ci, vp, vp]),
 }
 
 _lib = None

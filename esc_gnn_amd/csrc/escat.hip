@@ -24,15 +24,16 @@
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/escat.h"
+#include "escat_internal.h"
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
-static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-static int fail(int code, const char *fmt, ...)
+int escat_fail(int code, const char *fmt, ...)      // shared with escat_build.hip (escat_internal.h)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
     return code;
 }
+#define fail escat_fail
 extern "C" const char *escat_last_error(void) { return g_err; }
 extern "C" int escat_abi_version(void) { return 1; }
 

@@ -1,0 +1,396 @@
+// escat_build.hip -- gfx950 kernels for the P / Q operator build of ESc-GNN
+// (reference: data_processing/process_pyg_data.py:640-919 and the kNN graph of
+// data_processing/ellipsoid_data_classes.py:209-211), batched over the graphs of
+// a dataset.  One workgroup owns one graph; its points, the kNN lists and an
+// n x n adjacency bitmap live in LDS.
+//
+//   B0  k_knn            brute-force kNN per graph (fp64 squared distances, the
+//                        k smallest kept sorted in registers), no self loops
+//   B0' k_sym_count/fill symmetrise through an LDS bitmap (bit (i,j) and (j,i)
+//                        per kNN edge + the diagonal); a row's set bits, scanned
+//                        in order, ARE its sorted, de-duplicated CSR row
+//   B1  (in k_sym_fill)  P = 1/2 (I + D^-1 A): 0.5 on the diagonal, 0.5 * (1/deg)
+//                        elsewhere, same fp32 operations as get_P (:586-598)
+//   B2  k_local_frames   per node: M = sum_j w_j^2 (v_j - c)(v_j - c)^T over its
+//                        neighbours (kernel weights :79-138), fp64 cyclic Jacobi
+//                        -> O_i = eigenvectors by descending eigenvalue = the
+//                        left singular vectors of C_i (:238-286, :330-451)
+//   B3  k_q_blocks       per P-nonzero: column-dot sign alignment (:290-312) or
+//                        the literal "procrustes" formula (:315-327, which for
+//                        orthogonal frames equals (O_i O_j^T)^2), block =
+//                        p_ij * O_i O_j'^T in BSR-3 order = P's nonzero order
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/escat.h"
+#include "escat_internal.h"
+
+#define fail escat_fail
+#define CHECK_LAUNCH(what)                                                              \
+    do { hipError_t e_ = hipGetLastError();                                             \
+         if (e_ != hipSuccess) return fail(ESCAT_ELAUNCH, "%s: %s", what, hipGetErrorString(e_)); } while (0)
+
+#define BUILD_NT 256
+#define KMAX 32
+
+// ------------------------------------------------------------------ B0: kNN
+// knn[(gs + i) * k + s] = LOCAL index of the s-th nearest neighbour of node i (ascending distance,
+// ties -> smaller index), or -1 when the graph has fewer than k+1 nodes.
+template <int K>
+__global__ void __launch_bounds__(BUILD_NT)
+k_knn(const float *__restrict__ pos, const int *__restrict__ graph_ptr, int k, int *__restrict__ knn)
+{
+    extern __shared__ float sp[];                 // n * 3 positions
+    const int gs = graph_ptr[blockIdx.x], n = graph_ptr[blockIdx.x + 1] - gs;
+    for (int i = threadIdx.x; i < n * 3; i += BUILD_NT) sp[i] = pos[(int64_t)gs * 3 + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += BUILD_NT) {
+        double bd[K]; int bi[K];
+#pragma unroll
+        for (int s = 0; s < K; ++s) { bd[s] = 1e300; bi[s] = -1; }
+        const double xi = sp[3 * i], yi = sp[3 * i + 1], zi = sp[3 * i + 2];
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            const double dx = xi - (double)sp[3 * j], dy = yi - (double)sp[3 * j + 1], dz = zi - (double)sp[3 * j + 2];
+            const double d = dx * dx + dy * dy + dz * dz;
+            if (d < bd[K - 1]) {
+                bd[K - 1] = d; bi[K - 1] = j;
+#pragma unroll
+                for (int s = K - 1; s > 0; --s) {
+                    if (bd[s] < bd[s - 1]) {
+                        const double td = bd[s]; bd[s] = bd[s - 1]; bd[s - 1] = td;
+                        const int ti = bi[s]; bi[s] = bi[s - 1]; bi[s - 1] = ti;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < K; ++s)
+            if (s < k) knn[((int64_t)gs + i) * k + s] = bi[s];
+    }
+}
+
+// ------------------------------------------------------------------ symmetrise via LDS bitmap
+__device__ __forceinline__ void fill_bitmap(unsigned *bm, int n, int wpr, const int *__restrict__ knn, int gs, int k)
+{
+    for (int i = threadIdx.x; i < n * wpr; i += BUILD_NT) bm[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += BUILD_NT) {
+        atomicOr(&bm[i * wpr + (i >> 5)], 1u << (i & 31));                    // the diagonal of P
+        for (int s = 0; s < k; ++s) {
+            const int j = knn[((int64_t)gs + i) * k + s];
+            if (j < 0) continue;
+            atomicOr(&bm[i * wpr + (j >> 5)], 1u << (j & 31));
+            atomicOr(&bm[j * wpr + (i >> 5)], 1u << (i & 31));
+        }
+    }
+    __syncthreads();
+}
+
+// pass 1: rowlen[gs + i] = nonzeros of row i (diagonal included); graph_nnz[g] = their sum
+__global__ void __launch_bounds__(BUILD_NT)
+k_sym_count(const int *__restrict__ knn, const int *__restrict__ graph_ptr, int k, int *__restrict__ rowlen,
+            int *__restrict__ graph_nnz)
+{
+    extern __shared__ unsigned bm[];
+    __shared__ int total;
+    const int gs = graph_ptr[blockIdx.x], n = graph_ptr[blockIdx.x + 1] - gs;
+    const int wpr = (n + 31) >> 5;
+    if (threadIdx.x == 0) total = 0;
+    fill_bitmap(bm, n, wpr, knn, gs, k);
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += BUILD_NT) {
+        int c = 0;
+        for (int w = 0; w < wpr; ++w) c += __popc(bm[i * wpr + w]);
+        rowlen[gs + i] = c;
+        mine += c;
+    }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) graph_nnz[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of graph_nnz[B] -> graph_off[B+1]  (B up to ~1e6)
+__global__ void __launch_bounds__(1024)
+k_scan_graphs(const int *__restrict__ graph_nnz, int B, int *__restrict__ graph_off, int *__restrict__ nnz_out)
+{
+    __shared__ long long part[1024];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int b0 = t * per, b1 = min(B, b0 + per);
+    long long s = 0;
+    for (int b = b0; b < b1; ++b) s += graph_nnz[b];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long run = t ? part[t - 1] : 0;
+    for (int b = b0; b < b1; ++b) { graph_off[b] = (int)run; run += graph_nnz[b]; }
+    if (t == 1023) { graph_off[B] = (int)part[1023]; *nnz_out = part[1023] > 0x7fffffffLL ? -1 : (int)part[1023]; }
+}
+
+// pass 2: rowptr, col (global ids, ascending) and the lazy-walk values of P
+__global__ void __launch_bounds__(BUILD_NT)
+k_sym_fill(const int *__restrict__ knn, const int *__restrict__ graph_ptr, int k, const int *__restrict__ graph_off,
+           int *__restrict__ rowptr, int *__restrict__ col, float *__restrict__ pval, int64_t cap, int n_graphs)
+{
+    extern __shared__ unsigned bm[];
+    __shared__ int scan[BUILD_NT];
+    const int gs = graph_ptr[blockIdx.x], n = graph_ptr[blockIdx.x + 1] - gs;
+    const int wpr = (n + 31) >> 5;
+    fill_bitmap(bm, n, wpr, knn, gs, k);
+    // per-thread contiguous chunk of rows -> block scan of chunk sums
+    const int per = (n + BUILD_NT - 1) / BUILD_NT;
+    const int r0 = min(n, (int)threadIdx.x * per), r1 = min(n, r0 + per);
+    int mine = 0;
+    for (int i = r0; i < r1; ++i)
+        for (int w = 0; w < wpr; ++w) mine += __popc(bm[i * wpr + w]);
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < BUILD_NT; off <<= 1) {
+        const int v = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int e = graph_off[blockIdx.x] + (threadIdx.x ? scan[threadIdx.x - 1] : 0);
+    for (int i = r0; i < r1; ++i) {
+        rowptr[gs + i] = e;
+        int cnt = 0;
+        for (int w = 0; w < wpr; ++w) cnt += __popc(bm[i * wpr + w]);
+        const float D = (float)(cnt - 1);
+        const float dinv = D > 0.f ? 1.0f / D : 0.f;
+        const float off_val = 0.5f * (dinv * 1.0f);
+        for (int w = 0; w < wpr; ++w) {
+            unsigned bits = bm[i * wpr + w];
+            while (bits) {
+                const int j = (w << 5) + __ffs(bits) - 1;
+                bits &= bits - 1;
+                if (e < cap) { col[e] = gs + j; pval[e] = (j == i) ? 0.5f : off_val; }
+                ++e;
+            }
+        }
+    }
+    if (blockIdx.x == n_graphs - 1 && threadIdx.x == BUILD_NT - 1) rowptr[gs + n] = graph_off[n_graphs];
+}
+
+// ------------------------------------------------------------------ B2: local PCA frames
+// kernel weights of get_local_pca_kernel_weights (process_pyg_data.py:79-138), fp32 like the reference
+__device__ __forceinline__ float pca_weight(float r, int kernel, float eps, int has_eps, float r_cut, int has_rcut, int take_sqrt)
+{
+    float w;
+    if (kernel == 0) {                            // gaussian
+        w = has_eps ? expf(-(r * r) / eps) : expf(-(r * r));
+        if (has_rcut) w = r < r_cut ? w : 0.f;
+    } else if (kernel == 1) {                     // cosine_cutoff
+        w = 0.5f * (cosf(3.14159265358979323846f * r / r_cut) + 1.0f);
+        w = r < r_cut ? w : 0.f;
+        w = fmaxf(w, 0.f);
+    } else {                                      // epanechnikov
+        const float q = r / r_cut;
+        w = 1.0f - q * q;
+        w = r < r_cut ? w : 0.f;
+        w = fmaxf(w, 0.f);
+    }
+    return take_sqrt ? sqrtf(w) : w;
+}
+
+// eigen-decomposition of a symmetric 3x3 (fp64 cyclic Jacobi); V columns = eigenvectors, sorted by descending eigenvalue
+__device__ void jacobi3(double A[3][3], double V[3][3], double ev[3])
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-22 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int r = 0; r < 3; ++r) {             // A <- A J
+                    const double arp = A[r][p], arq = A[r][q];
+                    A[r][p] = c * arp - s * arq; A[r][q] = s * arp + c * arq;
+                }
+                for (int r = 0; r < 3; ++r) {             // A <- J^T A
+                    const double apr = A[p][r], aqr = A[q][r];
+                    A[p][r] = c * apr - s * aqr; A[q][r] = s * apr + c * aqr;
+                }
+                for (int r = 0; r < 3; ++r) {
+                    const double vrp = V[r][p], vrq = V[r][q];
+                    V[r][p] = c * vrp - s * vrq; V[r][q] = s * vrp + c * vrq;
+                }
+            }
+    }
+    ev[0] = A[0][0]; ev[1] = A[1][1]; ev[2] = A[2][2];
+    for (int a = 0; a < 2; ++a)                           // selection sort, descending
+        for (int b = a + 1; b < 3; ++b)
+            if (ev[b] > ev[a]) {
+                const double te = ev[a]; ev[a] = ev[b]; ev[b] = te;
+                for (int r = 0; r < 3; ++r) { const double tv = V[r][a]; V[r][a] = V[r][b]; V[r][b] = tv; }
+            }
+}
+
+// frames[i][a][c] = component a of the c-th left singular vector of C_i; n_isolated counts nodes without neighbours
+__global__ void __launch_bounds__(256)
+k_local_frames(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ pos, int64_t n,
+               int kernel, float eps, int has_eps, float r_cut, int has_rcut, int take_sqrt, int mean_recenter,
+               float *__restrict__ frames, int *__restrict__ n_isolated)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    float cx = xi, cy = yi, cz = zi;
+    int cnt = 0;
+    for (int e = e0; e < e1; ++e) cnt += col[e] != i;
+    if (cnt == 0) { atomicAdd(n_isolated, 1); for (int q = 0; q < 9; ++q) frames[9 * i + q] = 0.f; return; }
+    if (mean_recenter) {                          // mean over [x_i; neighbours] (process_pyg_data.py:377-388)
+        float sx = xi, sy = yi, sz = zi;
+        for (int e = e0; e < e1; ++e) {
+            const int j = col[e];
+            if (j == i) continue;
+            sx += pos[3 * (int64_t)j]; sy += pos[3 * (int64_t)j + 1]; sz += pos[3 * (int64_t)j + 2];
+        }
+        const float inv = 1.0f / (float)(cnt + 1);
+        cx = sx * inv; cy = sy * inv; cz = sz * inv;
+    }
+    double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int e = e0; e < e1; ++e) {
+        const int j = col[e];
+        if (j == i) continue;
+        const float vx = pos[3 * (int64_t)j] - cx, vy = pos[3 * (int64_t)j + 1] - cy, vz = pos[3 * (int64_t)j + 2] - cz;
+        const float r = sqrtf(vx * vx + vy * vy + vz * vz);
+        const float w = pca_weight(r, kernel, eps, has_eps, r_cut, has_rcut, take_sqrt);
+        const double ux = (double)(w * vx), uy = (double)(w * vy), uz = (double)(w * vz);   // a column of C_i, fp32 like the reference
+        M[0][0] += ux * ux; M[0][1] += ux * uy; M[0][2] += ux * uz;
+        M[1][1] += uy * uy; M[1][2] += uy * uz; M[2][2] += uz * uz;
+    }
+    M[1][0] = M[0][1]; M[2][0] = M[0][2]; M[2][1] = M[1][2];
+    double V[3][3], ev[3];
+    jacobi3(M, V, ev);
+    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 3; ++c) frames[9 * i + 3 * a + c] = (float)V[a][c];
+}
+
+// ------------------------------------------------------------------ B3: Q blocks on P's pattern
+__global__ void __launch_bounds__(256)
+k_q_blocks(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ pval,
+           const float *__restrict__ frames, int64_t n, int enforce_sign, int procrustes, float *__restrict__ blk)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float Oi[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Oi[q] = frames[9 * i + q];
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const int64_t j = col[e];
+        float Oj[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Oj[q] = frames[9 * j + q];
+        float R[9];
+        if (enforce_sign && procrustes) {
+            // S = O_i^T O_j is orthogonal, its polar factor U V^T is S itself: O_j' = O_j S, O_ij = O_i O_j'^T = (O_i O_j^T)^2
+            float A[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) A[3 * a + b] = Oi[3 * a] * Oj[3 * b] + Oi[3 * a + 1] * Oj[3 * b + 1] + Oi[3 * a + 2] * Oj[3 * b + 2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) R[3 * a + b] = A[3 * a] * A[b] + A[3 * a + 1] * A[3 + b] + A[3 * a + 2] * A[6 + b];
+        } else {
+            float s[3] = {1.f, 1.f, 1.f};
+            if (enforce_sign) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float d = Oi[c] * Oj[c] + Oi[3 + c] * Oj[3 + c] + Oi[6 + c] * Oj[6 + c];
+                    s[c] = d >= 0.0f ? 1.f : -1.f;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    R[3 * a + b] = Oi[3 * a] * (s[0] * Oj[3 * b]) + Oi[3 * a + 1] * (s[1] * Oj[3 * b + 1]) + Oi[3 * a + 2] * (s[2] * Oj[3 * b + 2]);
+        }
+        const float p = pval[e];
+        float *o = blk + (int64_t)e * 9;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[q] = p * R[q];
+    }
+}
+
+// ------------------------------------------------------------------ host
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+extern "C" size_t escat_build_workspace_bytes(int64_t n_nodes, int n_graphs, int k)
+{
+    if (n_nodes < 0 || n_graphs < 0 || k < 1) return 0;
+    // knn lists + row lengths + per-graph totals + per-graph offsets
+    return ((size_t)n_nodes * (size_t)k + (size_t)n_nodes + 2 * (size_t)n_graphs + 8) * sizeof(int32_t);
+}
+
+extern "C" int escat_build_knn_P(const float *pos, const int32_t *graph_ptr, int n_graphs, int64_t n_nodes, int max_graph_nodes,
+                                 int k, int32_t *rowptr, int32_t *col, float *pval, int64_t cap, int32_t *nnz_out,
+                                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!pos || !graph_ptr || !rowptr || !col || !pval || !nnz_out) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (k < 1 || k > KMAX) return fail(ESCAT_ERANGE, "k=%d outside [1,%d]", k, KMAX);
+    if (n_graphs < 1 || n_nodes < 1) return fail(ESCAT_EINVAL, "empty input");
+    if (n_nodes >= (int64_t)1 << 31) return fail(ESCAT_ERANGE, "n_nodes >= 2^31");
+    const int wpr = (max_graph_nodes + 31) / 32;
+    const size_t lds_bm = (size_t)max_graph_nodes * wpr * 4, lds_pos = (size_t)max_graph_nodes * 12;
+    if (max_graph_nodes < 1 || lds_bm > 150 * 1024)
+        return fail(ESCAT_ERANGE, "max_graph_nodes=%d: the LDS adjacency bitmap supports graphs of up to ~1090 nodes", max_graph_nodes);
+    const size_t need = escat_build_workspace_bytes(n_nodes, n_graphs, k);
+    if (!workspace || workspace_bytes < need) return fail(ESCAT_EWORKSPACE, "workspace %zu B < %zu B needed", workspace_bytes, need);
+    if (cap < n_nodes) return fail(ESCAT_EINVAL, "cap smaller than the number of nodes");
+    int32_t *knn = (int32_t *)workspace, *rowlen = knn + n_nodes * k, *gnnz = rowlen + n_nodes, *goff = gnnz + n_graphs;
+    hipStream_t st = S(stream);
+#define KNN(KK) hipLaunchKernelGGL((k_knn<KK>), dim3(n_graphs), dim3(BUILD_NT), lds_pos, st, pos, graph_ptr, k, knn)
+    if (k <= 4) KNN(4); else if (k <= 8) KNN(8); else if (k <= 16) KNN(16); else KNN(32);
+#undef KNN
+    if (lds_bm > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_sym_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);
+        (void)hipFuncSetAttribute((const void *)k_sym_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bm);
+    }
+    hipLaunchKernelGGL(k_sym_count, dim3(n_graphs), dim3(BUILD_NT), lds_bm, st, knn, graph_ptr, k, rowlen, gnnz);
+    hipLaunchKernelGGL(k_scan_graphs, dim3(1), dim3(1024), 0, st, gnnz, n_graphs, goff, nnz_out);
+    hipLaunchKernelGGL(k_sym_fill, dim3(n_graphs), dim3(BUILD_NT), lds_bm, st, knn, graph_ptr, k, goff, rowptr, col, pval, cap, n_graphs);
+    CHECK_LAUNCH("escat_build_knn_P");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_build_frames(const int32_t *rowptr, const int32_t *col, const float *pos, int64_t n_nodes,
+                                  int kernel, float gaussian_eps, int has_eps, float r_cut, int has_rcut, int take_sqrt,
+                                  int mean_recenter, float *frames, int32_t *n_isolated, void *stream)
+{
+    if (!rowptr || !col || !pos || !frames || !n_isolated) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (kernel < 0 || kernel > 2) return fail(ESCAT_EINVAL, "kernel must be 0 (gaussian), 1 (cosine_cutoff) or 2 (epanechnikov)");
+    if (kernel != 0 && !has_rcut) return fail(ESCAT_EINVAL, "r_cut must be provided for cutoff kernels");
+    if (n_nodes <= 0) return n_nodes == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative size");
+    hipLaunchKernelGGL(k_local_frames, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, S(stream), rowptr, col, pos, n_nodes,
+                       kernel, gaussian_eps, has_eps, r_cut, has_rcut, take_sqrt, mean_recenter, frames, n_isolated);
+    CHECK_LAUNCH("escat_build_frames");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_build_Q_bsr3(const int32_t *rowptr, const int32_t *col, const float *pval, const float *frames,
+                                  int64_t n_nodes, int enforce_sign, int procrustes, float *blk, void *stream)
+{
+    if (!rowptr || !col || !pval || !frames || !blk) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n_nodes <= 0) return n_nodes == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative size");
+    hipLaunchKernelGGL(k_q_blocks, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, S(stream), rowptr, col, pval, frames,
+                       n_nodes, enforce_sign, procrustes, blk);
+    CHECK_LAUNCH("escat_build_Q_bsr3");
+    return ESCAT_OK;
+}

@@ -102,12 +102,16 @@ def ellipsoid_batch(B, n, k, seed=457892, with_q=True, frames_seed=12345, worker
                 graph_ptr=(np.arange(B + 1) * n).astype(np.int32), nnz=int(col.shape[0]), N=B * n)
 
 
-def single_cloud(n, k, seed=457892, workers=-1, frames_seed=12345):
-    """cfg3: one ellipsoid cloud (a,b,c)=(3,1,1) with n points, kNN k; Q in BSR-3."""
+def single_cloud(n, k, seed=457892, workers=-1, frames_seed=12345, sort_axis=None):
+    """cfg3: one ellipsoid cloud (a,b,c)=(3,1,1) with n points, kNN k; Q in BSR-3.
+    sort_axis: None keeps the sampler's random node order (the reference's); 0/1/2 sorts the nodes along that
+    coordinate first (a locality experiment: neighbours then have nearby indices)."""
     rng = np.random.RandomState(seed)
     phi = rng.uniform(0, 2 * np.pi, n)
     theta = np.arccos(2 * rng.uniform(0, 1, n) - 1)
     pos = np.column_stack([3.0 * np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)]).astype(np.float32)
+    if sort_axis is not None:
+        pos = pos[np.argsort(pos[:, sort_axis], kind="stable")]
     rowptr, col = knn_sym_csr(pos, k, workers=workers)
     pval = lazy_walk_values(rowptr, col)
     blk = q_blocks_from_frames(rowptr, col, pval, random_frames(n, frames_seed))

@@ -165,6 +165,43 @@ int escat_scatter_orders_f32(const float *x0, const float *W1, int64_t rows, int
 int escat_scatter_orders_bwd_f32(const float *W1, const float *dW, int64_t rows, int F,
                                  int second_order, float *dx0, float *dW1, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Operator build (process_pyg_data, data_processing/process_pyg_data.py:640-919),
+ * batched over the graphs of a dataset.  pos is (n_nodes, 3) fp32, graph_ptr
+ * int32[n_graphs+1] gives each graph's node range.
+ * ------------------------------------------------------------------------- */
+
+/* workspace bytes for escat_build_knn_P. */
+size_t escat_build_workspace_bytes(int64_t n_nodes, int n_graphs, int k);
+
+/* kNN graph (k nearest, no self loops: knn_graph, ellipsoid_data_classes.py:209)
+ * -> symmetrised (to_undirected, :211) -> P = 1/2 (I + D^-1 A) (get_P,
+ * process_pyg_data.py:499-600, unit edge weights) in CSR with sorted columns,
+ * diagonal included: exactly the coalesced pattern of the reference's P.
+ * cap = capacity of col / pval; n_nodes*(2k+1) always suffices.  *nnz_out
+ * (device) receives the number of nonzeros.  Graphs of up to ~1090 nodes. */
+int escat_build_knn_P(const float *pos, const int32_t *graph_ptr, int n_graphs, int64_t n_nodes,
+                      int max_graph_nodes, int k, int32_t *rowptr, int32_t *col, float *pval,
+                      int64_t cap, int32_t *nnz_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Local-PCA frames O_i (get_C_i_dict :330-451 + get_l_singular_vecs :238-286):
+ * frames[i][a][c] = component a of the c-th left singular vector of
+ * C_i = (w_j (v_j - v_i))_j over the neighbours j of i in the CSR pattern
+ * (entries with col == row are skipped).  kernel: 0 gaussian (exp(-r^2/eps),
+ * or exp(-r^2) without eps), 1 cosine_cutoff, 2 epanechnikov (:79-138);
+ * take_sqrt as the reference's default.  *n_isolated (device, caller zeroes)
+ * counts nodes without neighbours (the reference raises KeyError for them). */
+int escat_build_frames(const int32_t *rowptr, const int32_t *col, const float *pos, int64_t n_nodes,
+                       int kernel, float gaussian_eps, int has_eps, float r_cut, int has_rcut,
+                       int take_sqrt, int mean_recenter, float *frames, int32_t *n_isolated, void *stream);
+
+/* Q blocks on P's pattern (calc_O_ij :454-493, loop :823-857): blk[e] =
+ * pval[e] * O_i O_j'^T with O_j' = column-dot sign alignment of O_j to O_i
+ * (procrustes = 0) or the reference's Procrustes formula (procrustes = 1);
+ * enforce_sign = 0 skips the alignment.  blk is BSR-3 on (rowptr, col). */
+int escat_build_Q_bsr3(const int32_t *rowptr, const int32_t *col, const float *pval, const float *frames,
+                       int64_t n_nodes, int enforce_sign, int procrustes, float *blk, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,187 @@
+"""
+GPU parity tests of the P / Q operator build (esc_gnn_amd/process_pyg_data.py -> escat_build_* in libescat.so)
+against the goldens generated from the reference's process_pyg_data and against oracle/builder_oracle.py.
+
+Index structure (P CSR pattern, Q block pattern and emission order) and P values are compared BIT-EXACT.
+Q values: the reference takes O_i from a fp32 LAPACK SVD of C_i, the kernel from a fp64 Jacobi eigensolver of
+C_i C_i^T; both are exact up to rounding, but where two singular values nearly coincide the frame is ill-conditioned
+(SURVEY.md §7), so blocks are compared with a gap-aware tolerance and globally through the invariants.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import builder_oracle as bo
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _cases(bg):
+    for ci, c in enumerate(bg["cases"]):
+        n, k, align, rec = str(c).split(",")
+        yield ci, int(n), int(k), align, bool(int(rec))
+
+
+class _Data(dict):
+    __getattr__ = dict.get
+
+
+def _gaps(pos, ei, eps, rec):
+    """smallest relative singular-value gap per node (conditioning of its frame)."""
+    O = bo.local_frames(pos, ei, {"kernel": "gaussian", "gaussian_eps": eps}, rec)
+    v = torch.from_numpy(pos)
+    gaps = np.ones(pos.shape[0])
+    nb = {}
+    for s, t in zip(ei[0].tolist(), ei[1].tolist()):
+        nb.setdefault(s, []).append(t)
+    for i, l in nb.items():
+        V = v[l] - (v[[i] + l].mean(0) if rec else v[i])
+        w = bo.kernel_weights(V.norm(dim=1), "gaussian", gaussian_eps=eps)
+        s = torch.linalg.svdvals((w[:, None] * V).T.double())
+        gaps[i] = float(min(s[0] - s[1], s[1] - s[2]) / s[0])
+    return gaps
+
+
+def test_process_pyg_data_vs_goldens(bg):
+    from esc_gnn_amd.process_pyg_data import process_pyg_data
+    dev = _dev()
+    worst = 0.0
+    for ci, n, k, align, rec in _cases(bg):
+        p = f"g{ci}_"
+        eps = float(bg[p + "eps"])
+        data = _Data(pos=torch.from_numpy(bg[p + "pos"]), edge_index=torch.from_numpy(bg[p + "edge_index"]), num_nodes=n)
+        for dt in ("float32", "float16"):
+            out = process_pyg_data(data, data_i=ci, return_data_object=False, vector_feat_key="pos", device="cuda",
+                                   graph_construction=None, use_mean_recentering=rec,
+                                   local_pca_kernel_fn_kwargs={"kernel": "gaussian", "gaussian_eps": eps},
+                                   sing_vect_align_method=align, hdf5_tensor_dtype=dt)
+            assert out["original_idx"] == ci
+            assert np.array_equal(out["P"]["indices"].cpu().numpy(), bg[p + "P_indices"])            # bit-exact structure
+            assert np.array_equal(out["Q"]["indices"].cpu().numpy(), bg[p + "Q_indices"])
+            assert tuple(out["P"]["size"]) == tuple(bg[p + "P_size"]) and tuple(out["Q"]["size"]) == tuple(bg[p + "Q_size"])
+            suffix = "f32" if dt == "float32" else "f16"
+            assert np.array_equal(out["P"]["values"].cpu().numpy(), bg[p + "P_values_" + suffix])    # bit-exact values
+            qv = out["Q"]["values"].cpu().numpy().astype(np.float32).reshape(-1, 3, 3)
+            ref = bg[p + "Q_values_" + suffix].astype(np.float32).reshape(-1, 3, 3)
+            if align == "procrustes":
+                continue        # depends on the SVD's arbitrary column signs: checked in test_procrustes_formula
+            if dt == "float32":
+                gaps = _gaps(bg[p + "pos"], bg[p + "edge_index"], eps, rec)
+                Pi = bg[p + "P_indices"]
+                g = np.minimum(gaps[Pi[0]], gaps[Pi[1]])
+                err = np.abs(qv - ref).max(axis=(1, 2))
+                worst = max(worst, float((err * g).max()))
+                assert (err <= 2e-6 / np.maximum(g, 1e-6) + 2e-6).all(), (ci, float((err * g).max()))
+            else:
+                assert np.abs(qv - ref).max() <= 2e-3
+    print("worst gap-scaled Q error", worst)
+
+
+def test_procrustes_formula(bg):
+    """the reference's 'procrustes' alignment (process_pyg_data.py:315-327) is NOT invariant to the arbitrary column
+    signs LAPACK picks for O_i, so goldens cannot pin it for a different eigensolver; pin the kernel's formula instead:
+    with the kernel's own frames, blocks must equal the oracle's literal U V^T computation."""
+    from esc_gnn_amd.process_pyg_data import frames_and_Q, _get_P_csr
+    dev = _dev()
+    pos = torch.from_numpy(bg["g5_pos"]).to(dev)
+    rowptr, col, pval, _ = _get_P_csr(torch.from_numpy(bg["g5_edge_index"]), 48, None, True, dev)
+    for method in ("procrustes", "column_dot"):
+        frames, blk = frames_and_Q(rowptr, col, pval, pos, {"kernel": "gaussian", "gaussian_eps": float(bg["g5_eps"])},
+                                   sing_vect_align_method=method)
+        F, B = frames.cpu(), blk.cpu()
+        rp = rowptr.cpu().numpy()
+        for i in range(48):
+            for e in range(rp[i], rp[i + 1]):
+                j = int(col[e])
+                ref = float(pval[e]) * bo.calc_O_ij(F[i], F[j], True, method)
+                assert (B[e] - ref).abs().max() < 2e-5, (method, i, j)
+        assert (torch.einsum("nac,nbc->nab", F, F) - torch.eye(3)).abs().max() < 1e-6       # frames orthonormal
+
+
+def test_other_kernels_and_colnorm(bg):
+    from esc_gnn_amd.process_pyg_data import process_pyg_data
+    _dev()
+    data = _Data(pos=torch.from_numpy(bg["g0_pos"]), edge_index=torch.from_numpy(bg["g0_edge_index"]), num_nodes=32)
+    out = process_pyg_data(data, return_data_object=False, graph_construction=None, hdf5_tensor_dtype="float32",
+                           local_pca_kernel_fn_kwargs={"kernel": "epanechnikov", "r_cut": 5.0})
+    assert np.abs(out["Q"]["values"].cpu().numpy() - bg["g0_epan_Q_values_f32"]).max() <= 1e-4
+    out = process_pyg_data(data, return_data_object=False, graph_construction=None, hdf5_tensor_dtype="float32",
+                           row_normalize=False,
+                           local_pca_kernel_fn_kwargs={"kernel": "gaussian", "gaussian_eps": float(bg["g0_eps"])})
+    assert np.array_equal(out["P"]["indices"].cpu().numpy(), bg["g0_colnorm_P_indices"])
+    assert np.array_equal(out["P"]["values"].cpu().numpy(), bg["g0_colnorm_P_values_f32"])
+    assert np.abs(out["Q"]["values"].cpu().numpy() - bg["g0_colnorm_Q_values_f32"]).max() <= 1e-4
+    with pytest.raises(NotImplementedError):
+        process_pyg_data(data, graph_construction="radius")
+    with pytest.raises(ValueError):
+        process_pyg_data(data, graph_construction=None, local_pca_kernel_fn_kwargs={"kernel": "cosine_cutoff"})
+    # isolated node -> KeyError like the reference
+    ei = torch.from_numpy(bg["g0_edge_index"])
+    keep = (ei[0] != 5) & (ei[1] != 5)
+    with pytest.raises(KeyError):
+        process_pyg_data(_Data(pos=data["pos"], edge_index=ei[:, keep], num_nodes=32), return_data_object=False,
+                         graph_construction=None, local_pca_kernel_fn_kwargs={"kernel": "gaussian", "gaussian_eps": 1.0})
+
+
+def test_batched_knn_builder(bg):
+    """kNN + symmetrise + P on the GPU for a batch of ragged graphs == per-graph oracle (pattern and P bit-exact),
+    Q blocks satisfy the invariants of SURVEY.md §4 and feed get_Batch_Wjxs directly."""
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch, coo_parts
+    from esc_gnn_amd import get_Batch_Wjxs, synthetic
+    dev = _dev()
+    sizes = [32, 64, 128, 64, 128, 48, 500, 7, 200]
+    rng = np.random.RandomState(5)
+    clouds = [synthetic.ellipsoid_clouds(1, n, seed=int(rng.randint(1 << 30)))[0] for n in sizes]
+    for k in (5, 10):
+        use = [c for c in clouds if c.shape[0] > k]
+        pos = np.concatenate(use)
+        gp = np.cumsum([0] + [c.shape[0] for c in use]).astype(np.int32)
+        b = build_PQ_batch(torch.from_numpy(pos).to(dev), torch.from_numpy(gp), k, {"kernel": "gaussian", "gaussian_eps": 0.05})
+        rp, col, pv = b["rowptr"].cpu().numpy(), b["col"].cpu().numpy(), b["pval"].cpu().numpy()
+        assert rp[-1] == b["nnz"] == col.shape[0]
+        for g, c in enumerate(use):
+            ei = bo.knn_sym_edges(c, k)
+            Pi, Pv = bo.get_P_coo(ei, c.shape[0])
+            parts = coo_parts(b, g, "float32")
+            assert np.array_equal(parts["P"]["indices"].cpu().numpy(), Pi.numpy()), (k, g)
+            assert np.array_equal(parts["P"]["values"].cpu().numpy(), Pv.numpy())
+            Qv = parts["Q"]["values"].cpu().numpy().reshape(-1, 3, 3)
+            R = Qv / Pv.numpy()[:, None, None]
+            assert np.abs(np.einsum("eab,ecb->eac", R, R) - np.eye(3)).max() < 1e-4          # blocks / p_ij are orthogonal
+            diag = (Pi[0] == Pi[1]).numpy()
+            assert np.abs(R[diag] - np.eye(3)).max() < 1e-5                                    # Q_ii = 1/2 I
+            # Q_ji / p_ji = (Q_ij / p_ij)^T
+            n = c.shape[0]
+            key = (Pi[0] * n + Pi[1]).numpy()
+            tkey = (Pi[1] * n + Pi[0]).numpy()
+            order = np.argsort(key)
+            tpos = order[np.searchsorted(key[order], tkey)]
+            assert np.abs(R[tpos] - R.transpose(0, 2, 1)).max() < 1e-4
+        # the batch feeds the scattering path with no ingest step
+        N = pos.shape[0]
+        W = get_Batch_Wjxs(torch.from_numpy(pos).to(dev).reshape(-1, 1), b["Q"], J=3)
+        assert W.shape == (3 * N, 1, 5) and torch.isfinite(W).all()
+        assert (W.sum(-1).reshape(-1) - torch.from_numpy(pos).to(dev).reshape(-1)).abs().max() < 1e-5
+
+
+def test_builder_vs_oracle_Q_blocks(bg):
+    """full Q of a fresh seeded graph vs the numpy/torch restatement (gap-aware)."""
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    from esc_gnn_amd import synthetic
+    dev = _dev()
+    c = synthetic.ellipsoid_clouds(1, 150, seed=4242)[0]
+    ei = bo.knn_sym_edges(c, 8)
+    eps = float(np.linalg.norm(c[ei[0]] - c[ei[1]], axis=1).mean() ** 2)
+    ref = bo.build_PQ(c, ei, {"kernel": "gaussian", "gaussian_eps": eps})
+    b = build_PQ_batch(torch.from_numpy(c).to(dev), torch.tensor([0, 150], dtype=torch.int32), 8,
+                       {"kernel": "gaussian", "gaussian_eps": eps})
+    gaps = _gaps(c, ei, eps, False)
+    Pi = ref["P"]["indices"]
+    g = np.minimum(gaps[Pi[0]], gaps[Pi[1]])
+    err = np.abs(b["blk"].cpu().numpy() - ref["Q"]["values"].reshape(-1, 3, 3)).max(axis=(1, 2))
+    assert (err <= 2e-6 / np.maximum(g, 1e-6) + 2e-6).all(), float((err * g).max())

@@ -168,7 +168,7 @@ def test_synthetic_batch_matches_reference_P(bg):
 def test_library_exports_every_declared_symbol():
     from esc_gnn_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "escat.h")).read()
-    declared = set(re.findall(r"\b(escat_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(escat_[A-Za-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()

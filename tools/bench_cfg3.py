@@ -12,11 +12,12 @@ def main():
     ap.add_argument("--J", type=int, default=6)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--sort-axis", type=int, default=None)
     ap.add_argument("--check", action="store_true", help="telescoping-sum property check on the result")
     args = ap.parse_args()
     from esc_gnn_amd import synthetic
     t0 = time.time()
-    b = synthetic.single_cloud(args.n, args.k, workers=min(16, os.cpu_count()))
+    b = synthetic.single_cloud(args.n, args.k, workers=min(16, os.cpu_count()), sort_axis=args.sort_axis)
     gen_s = time.time() - t0
     import torch
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain
