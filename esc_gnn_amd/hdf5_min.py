@@ -1,0 +1,309 @@
+"""
+Minimal HDF5 writer/reader for the ONE layout the reference uses for its operator files
+(writer: scripts/python/generate_ellipsoid_dataset.py:1185-1206 and
+scripts/python/parallel_process_dataset.py:193-230; reader: models/escgnn_data_classes.py:135-176):
+
+    /{P,Q}/{idx}/indices   int64   (2, nnz)
+    /{P,Q}/{idx}/values    float16 | float32 (nnz,)
+    /{P,Q}/{idx}/size      int64   (2,)
+    [/edge_index/{idx}/values, /edge_weight/{idx}/values, ...]   same shapes of objects
+
+Neither h5py nor libhdf5 exists in the build or GPU images, so this module writes the file format directly
+(HDF5 File Format Specification v3): superblock v2, version-2 object headers (Jenkins lookup3 checksums),
+new-style groups with compact link storage (Link Info + Link messages), datasets with contiguous layout
+(uncompressed -- the reference's reader does not require gzip, escgnn_data_classes.py:136-141).
+
+PARITY UNPINNED: with no HDF5 library available the files are validated only against the spec as restated in
+`read()` below and against the lookup3 test vectors; a cross-check with h5py is the first thing to do where it exists.
+"""
+import os
+import struct
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+_SIG = b"\x89HDF\r\n\x1a\n"
+
+
+# ------------------------------------------------------------------ Jenkins lookup3 (hashlittle, initval 0)
+def _rot(x, k):
+    return ((x << k) | (x >> (32 - k))) & 0xFFFFFFFF
+
+
+def lookup3(data: bytes, initval: int = 0) -> int:
+    M = 0xFFFFFFFF
+    n = len(data)
+    a = b = c = (0xdeadbeef + n + initval) & M
+    i = 0
+    while n > 12:
+        a = (a + int.from_bytes(data[i:i + 4], "little")) & M
+        b = (b + int.from_bytes(data[i + 4:i + 8], "little")) & M
+        c = (c + int.from_bytes(data[i + 8:i + 12], "little")) & M
+        a = (a - c) & M; a ^= _rot(c, 4); c = (c + b) & M
+        b = (b - a) & M; b ^= _rot(a, 6); a = (a + c) & M
+        c = (c - b) & M; c ^= _rot(b, 8); b = (b + a) & M
+        a = (a - c) & M; a ^= _rot(c, 16); c = (c + b) & M
+        b = (b - a) & M; b ^= _rot(a, 19); a = (a + c) & M
+        c = (c - b) & M; c ^= _rot(b, 4); b = (b + a) & M
+        i += 12; n -= 12
+    if n == 0:
+        return c
+    tail = data[i:i + n] + b"\x00" * (12 - n)
+    a = (a + int.from_bytes(tail[0:4], "little")) & M
+    b = (b + int.from_bytes(tail[4:8], "little")) & M
+    c = (c + int.from_bytes(tail[8:12], "little")) & M
+    c ^= b; c = (c - _rot(b, 14)) & M
+    a ^= c; a = (a - _rot(c, 11)) & M
+    b ^= a; b = (b - _rot(a, 25)) & M
+    c ^= b; c = (c - _rot(b, 16)) & M
+    a ^= c; a = (a - _rot(c, 4)) & M
+    b ^= a; b = (b - _rot(a, 14)) & M
+    c ^= b; c = (c - _rot(b, 24)) & M
+    return c
+
+
+# ------------------------------------------------------------------ message encoders
+def _datatype(dt: np.dtype) -> bytes:
+    dt = np.dtype(dt)
+    if dt == np.int64:
+        return struct.pack("<BBBBI", 0x10, 0x08, 0, 0, 8) + struct.pack("<HH", 0, 64)
+    if dt == np.int32:
+        return struct.pack("<BBBBI", 0x10, 0x08, 0, 0, 4) + struct.pack("<HH", 0, 32)
+    if dt == np.float32:
+        return struct.pack("<BBBBI", 0x11, 0x20, 31, 0, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+    if dt == np.float16:
+        return struct.pack("<BBBBI", 0x11, 0x20, 15, 0, 2) + struct.pack("<HHBBBBI", 0, 16, 10, 5, 0, 10, 15)
+    if dt == np.float64:
+        return struct.pack("<BBBBI", 0x11, 0x20, 63, 0, 8) + struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
+    raise TypeError(f"hdf5_min: unsupported dtype {dt}")
+
+
+def _dataspace(shape) -> bytes:
+    return struct.pack("<BBBB", 2, len(shape), 0, 1) + b"".join(struct.pack("<Q", int(d)) for d in shape)
+
+
+def _msg(mtype: int, body: bytes) -> bytes:
+    return struct.pack("<BHB", mtype, len(body), 0) + body
+
+
+def _ohdr(messages: bytes) -> bytes:
+    """version-2 object header, one chunk, 4-byte chunk-size field, no times."""
+    head = b"OHDR" + struct.pack("<BB", 2, 0x02) + struct.pack("<I", len(messages))
+    body = head + messages
+    return body + struct.pack("<I", lookup3(body))
+
+
+def _dataset_header(arr: np.ndarray, data_addr: int) -> bytes:
+    msgs = _msg(0x01, _dataspace(arr.shape))
+    msgs += _msg(0x03, _datatype(arr.dtype))
+    msgs += _msg(0x05, struct.pack("<BB", 3, 0x0A))                  # fill value v3: allocate late, write if set, no value (libhdf5 default)
+    msgs += _msg(0x08, struct.pack("<BBQQ", 3, 1, data_addr if arr.nbytes else UNDEF, arr.nbytes))   # contiguous layout
+    return _ohdr(msgs)
+
+
+def _group_header(links) -> bytes:
+    """links: list of (name, address). Link Info (compact storage) + one Link message per child."""
+    msgs = _msg(0x02, struct.pack("<BBQQ", 0, 0, UNDEF, UNDEF))      # link info: no creation order, no heap, no index
+    for name, addr in links:
+        nb = name.encode("utf-8")
+        if len(nb) < 256:
+            msgs += _msg(0x06, struct.pack("<BBB", 1, 0x00, len(nb)) + nb + struct.pack("<Q", addr))
+        else:
+            msgs += _msg(0x06, struct.pack("<BBH", 1, 0x01, len(nb)) + nb + struct.pack("<Q", addr))
+    return _ohdr(msgs)
+
+
+class H5Writer:
+    """
+    with H5Writer(path) as f:
+        f.write("P/0/indices", np.int64 array (2, nnz)) ...
+    Objects are appended as they come (data, then the dataset's header); group headers and the superblock are
+    written on close, to `path + '.tmp'` and renamed atomically like the reference
+    (generate_ellipsoid_dataset.py:1157-1213).
+    """
+
+    def __init__(self, path: str):
+        self.path = path
+        self.tmp = path + ".tmp"
+        self.f = open(self.tmp, "wb")
+        self.f.write(b"\x00" * 48)                                    # superblock placeholder
+        self.pos = 48
+        self.tree = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.close()
+        else:
+            self.f.close()
+            os.remove(self.tmp)
+
+    def _append(self, b: bytes, align: int = 8) -> int:
+        pad = (-self.pos) % align
+        if pad:
+            self.f.write(b"\x00" * pad)
+            self.pos += pad
+        addr = self.pos
+        self.f.write(b)
+        self.pos += len(b)
+        return addr
+
+    def write(self, path: str, arr) -> None:
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.byteorder == ">":
+            arr = arr.astype(arr.dtype.newbyteorder("<"))
+        parts = [p for p in path.split("/") if p]
+        node = self.tree
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+            if not isinstance(node, dict):
+                raise ValueError(f"{p} is a dataset, not a group")
+        if parts[-1] in node:
+            raise ValueError(f"{path} already exists")
+        data_addr = self._append(arr.tobytes()) if arr.nbytes else UNDEF
+        node[parts[-1]] = self._append(_dataset_header(arr, data_addr))
+
+    def _flush_group(self, node) -> int:
+        links = []
+        for name in node:
+            child = node[name]
+            links.append((name, self._flush_group(child) if isinstance(child, dict) else child))
+        return self._append(_group_header(links))
+
+    def close(self) -> None:
+        root = self._flush_group(self.tree)
+        eof = self.pos
+        sb = _SIG + struct.pack("<BBBB", 2, 8, 8, 0) + struct.pack("<QQQQ", 0, UNDEF, eof, root)
+        sb += struct.pack("<I", lookup3(sb))
+        self.f.seek(0)
+        self.f.write(sb)
+        self.f.close()
+        os.replace(self.tmp, self.path)
+
+
+# ------------------------------------------------------------------ reader (the subset the writer produces)
+_DT = {(0, 8): np.int64, (0, 4): np.int32, (1, 4): np.float32, (1, 2): np.float16, (1, 8): np.float64}
+
+
+class H5Reader:
+    """f = H5Reader(path); f["P"]["0"]["indices"][...] -> numpy array (mirrors the h5py calls of
+    models/escgnn_data_classes.py:136-141).  Verifies every checksum it passes."""
+
+    def __init__(self, path: str):
+        self.buf = np.memmap(path, dtype=np.uint8, mode="r")
+        b = bytes(self.buf[:48])
+        if b[:8] != _SIG or b[8] != 2:
+            raise ValueError("not an HDF5 file with a version-2 superblock")
+        if struct.unpack("<I", b[44:48])[0] != lookup3(b[:44]):
+            raise ValueError("superblock checksum mismatch")
+        self.eof, self.root = struct.unpack("<QQ", b[28:44])
+
+    def _messages(self, addr: int):
+        b = self.buf
+        if bytes(b[addr:addr + 4]) != b"OHDR" or b[addr + 4] != 2:
+            raise ValueError(f"no version-2 object header at {addr}")
+        flags = int(b[addr + 5])
+        szlen = 1 << (flags & 3)
+        p = addr + 6 + (16 if flags & 0x20 else 0) + (4 if flags & 0x10 else 0)
+        size = int.from_bytes(bytes(b[p:p + szlen]), "little")
+        p += szlen
+        end = p + size
+        if struct.unpack("<I", bytes(b[end:end + 4]))[0] != lookup3(bytes(b[addr:end])):
+            raise ValueError(f"object header checksum mismatch at {addr}")
+        out = []
+        while p + 4 <= end:
+            mtype, msize, _ = struct.unpack("<BHB", bytes(b[p:p + 4]))
+            p += 4 + (2 if flags & 0x04 else 0)
+            out.append((mtype, bytes(b[p:p + msize])))
+            p += msize
+        return out
+
+    def node(self, addr: int):
+        msgs = self._messages(addr)
+        types = [m[0] for m in msgs]
+        if 0x02 in types:
+            links = {}
+            for t, body in msgs:
+                if t != 0x06:
+                    continue
+                lflags = body[1]
+                q = 2
+                if lflags & 0x08:
+                    q += 1
+                if lflags & 0x04:
+                    q += 8
+                if lflags & 0x10:
+                    q += 1
+                ln = 1 << (lflags & 3)
+                nlen = int.from_bytes(body[q:q + ln], "little")
+                q += ln
+                links[body[q:q + nlen].decode()] = struct.unpack("<Q", body[q + nlen:q + nlen + 8])[0]
+            return _Group(self, links)
+        d = dict(msgs)
+        sp, ty, lay = d[0x01], d[0x03], d[0x08]
+        rank = sp[1]
+        shape = tuple(struct.unpack("<Q", sp[4 + 8 * i:12 + 8 * i])[0] for i in range(rank))
+        dtype = _DT[(ty[0] & 0x0F, struct.unpack("<I", ty[4:8])[0])]
+        if lay[0] != 3 or lay[1] != 1:
+            raise ValueError("only contiguous layout is supported")
+        daddr, dsize = struct.unpack("<QQ", lay[2:18])
+        return _Dataset(self, shape, np.dtype(dtype), daddr, dsize)
+
+    def __getitem__(self, key):
+        return self.node(self.root)[key]
+
+    def __contains__(self, key):
+        return key in self.node(self.root)
+
+    def keys(self):
+        return self.node(self.root).keys()
+
+    def close(self):
+        del self.buf
+
+
+class _Group:
+    def __init__(self, f, links):
+        self.f, self.links = f, links
+
+    def __getitem__(self, key):
+        node = self
+        for part in [p for p in key.split("/") if p]:
+            node = node.f.node(node.links[part])
+        return node
+
+    def __contains__(self, key):
+        return key in self.links
+
+    def keys(self):
+        return self.links.keys()
+
+
+class _Dataset:
+    def __init__(self, f, shape, dtype, addr, size):
+        self.f, self.shape, self.dtype, self.addr, self.size = f, shape, dtype, addr, size
+
+    def __getitem__(self, idx):
+        if self.size == 0:
+            return np.zeros(self.shape, self.dtype)[idx]
+        raw = np.frombuffer(bytes(self.f.buf[self.addr:self.addr + self.size]), dtype=self.dtype)
+        return raw.reshape(self.shape)[idx]
+
+
+# ------------------------------------------------------------------ the reference's operator file
+def write_operator_file(path, graphs, op_keys=("P", "Q")):
+    """graphs: iterable of (idx, dict) with dict[op] = {'indices','values','size'} (torch tensors or arrays),
+    i.e. what process_pyg_data(..., return_data_object=False) returns; optional 'edge_index'/'edge_weight'."""
+    def _np(x):
+        return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+    with H5Writer(path) as f:
+        for idx, d in graphs:
+            for op in op_keys:
+                f.write(f"{op}/{idx}/indices", _np(d[op]["indices"]).astype(np.int64))
+                f.write(f"{op}/{idx}/values", _np(d[op]["values"]))
+                f.write(f"{op}/{idx}/size", np.array(tuple(d[op]["size"]), dtype=np.int64))
+            if "edge_index" in d:
+                f.write(f"edge_index/{idx}/values", _np(d["edge_index"]).astype(np.int64))
+            if "edge_weight" in d:
+                f.write(f"edge_weight/{idx}/values", _np(d["edge_weight"]))

@@ -222,3 +222,52 @@ def process_pyg_data(
         parts["edge_index"] = edge_index.cpu().to(torch.int64)
         parts["edge_weight"] = A_vals.to(getattr(torch, hdf5_tensor_dtype)).cpu()
     return parts
+
+
+def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k: int,
+                       local_pca_kernel_fn_kwargs: Dict[str, Any], hdf5_tensor_dtype: str = "float16",
+                       chunk_graphs: int = 16384, **build_kwargs) -> Dict[str, Any]:
+    """
+    The P/Q -> HDF5 loop of scripts/python/generate_ellipsoid_dataset.py:1165-1213 for a whole dataset: graphs are
+    built on the GPU in chunks (build_PQ_batch), the per-graph COO arrays of the reference layout are formed on the
+    GPU for the whole chunk, copied to the host once and written by esc_gnn_amd.hdf5_min (atomic rename at the end).
+    """
+    import numpy as np
+    from .hdf5_min import H5Writer
+    dev = pos.device
+    gp_all = graph_ptr.to(torch.int64).cpu()
+    B = gp_all.numel() - 1
+    tdt = getattr(torch, hdf5_tensor_dtype)
+    total_nnz = 0
+    with H5Writer(path) as f:
+        for g0 in range(0, B, chunk_graphs):
+            g1 = min(B, g0 + chunk_graphs)
+            n0, n1 = int(gp_all[g0]), int(gp_all[g1])
+            gp = (gp_all[g0:g1 + 1] - n0).to(torch.int32)
+            b = build_PQ_batch(pos[n0:n1], gp.to(dev), k, local_pca_kernel_fn_kwargs, **build_kwargs)
+            total_nnz += b["nnz"]
+            rp = b["rowptr"].long()
+            n = n1 - n0
+            rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+            gid = torch.repeat_interleave(torch.arange(g1 - g0, device=dev), (gp[1:] - gp[:-1]).to(dev).long())
+            base = gp.to(dev).long()[gid]                                   # first node of each row's graph
+            lrow, lcol = rows - base[rows], b["col"].long() - base[rows]
+            eoff = rp[gp.to(dev).long()].cpu().numpy()                      # nnz offset of each graph
+            P_idx = torch.stack([lrow, lcol]).cpu().numpy()
+            P_val = b["pval"].to(tdt).cpu().numpy()
+            Q_val = b["blk"].reshape(-1).to(tdt).cpu().numpy()
+            a = torch.arange(3, device=dev)
+            Q_r = ((3 * lrow)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1).cpu().numpy()
+            Q_c = ((3 * lcol)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1).cpu().numpy()
+            gpn = gp.numpy()
+            for g in range(g1 - g0):
+                e0, e1 = int(eoff[g]), int(eoff[g + 1])
+                ng = int(gpn[g + 1] - gpn[g])
+                idx = g0 + g
+                f.write(f"P/{idx}/indices", P_idx[:, e0:e1])
+                f.write(f"P/{idx}/values", P_val[e0:e1])
+                f.write(f"P/{idx}/size", np.array([ng, ng], dtype=np.int64))
+                f.write(f"Q/{idx}/indices", np.stack([Q_r[9 * e0:9 * e1], Q_c[9 * e0:9 * e1]]))
+                f.write(f"Q/{idx}/values", Q_val[9 * e0:9 * e1])
+                f.write(f"Q/{idx}/size", np.array([3 * ng, 3 * ng], dtype=np.int64))
+    return {"graphs": B, "nnz": total_nnz, "path": path}

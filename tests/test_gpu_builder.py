@@ -185,3 +185,42 @@ def test_builder_vs_oracle_Q_blocks(bg):
     g = np.minimum(gaps[Pi[0]], gaps[Pi[1]])
     err = np.abs(b["blk"].cpu().numpy() - ref["Q"]["values"].reshape(-1, 3, 3)).max(axis=(1, 2))
     assert (err <= 2e-6 / np.maximum(g, 1e-6) + 2e-6).all(), float((err * g).max())
+
+
+def test_dataset_to_hdf5_and_back(tmp_path, bg):
+    """cfg5 in small: build a ragged dataset on the GPU, write the reference's HDF5 layout, read it back the way
+    models/escgnn_data_classes.py:135-143 does and run the scattering chain on the loaded operators."""
+    from esc_gnn_amd.process_pyg_data import write_dataset_hdf5, process_pyg_data
+    from esc_gnn_amd.hdf5_min import H5Reader
+    from esc_gnn_amd import get_Batch_Wjxs, synthetic
+    dev = _dev()
+    sizes = [32, 64, 48, 128, 20]
+    clouds = [synthetic.ellipsoid_clouds(1, n, seed=100 + n)[0] for n in sizes]
+    pos = torch.from_numpy(np.concatenate(clouds)).to(dev)
+    gp = torch.from_numpy(np.cumsum([0] + sizes).astype(np.int32))
+    kw = {"kernel": "gaussian", "gaussian_eps": 0.1}
+    path = str(tmp_path / "pq.h5")
+    info = write_dataset_hdf5(path, pos, gp, 5, kw, hdf5_tensor_dtype="float16", chunk_graphs=2)
+    assert info["graphs"] == 5
+    f = H5Reader(path)
+    assert set(f.keys()) == {"P", "Q"} and set(f["P"].keys()) == {str(i) for i in range(5)}
+    for g, c in enumerate(clouds):
+        ei = bo.knn_sym_edges(c, 5)
+        one = process_pyg_data(_Data(pos=torch.from_numpy(c), edge_index=torch.from_numpy(ei), num_nodes=c.shape[0]),
+                               return_data_object=False, graph_construction=None, local_pca_kernel_fn_kwargs=kw,
+                               hdf5_tensor_dtype="float16")
+        for op in ("P", "Q"):
+            grp = f[op][str(g)]
+            assert np.array_equal(grp["indices"][...], one[op]["indices"].cpu().numpy())
+            assert grp["values"].dtype == np.float16
+            assert np.array_equal(grp["values"][...], one[op]["values"].cpu().numpy())
+            assert tuple(grp["size"][...].tolist()) == tuple(one[op]["size"])
+        # the reference loader's construction (fp32 sparse COO from fp16 storage), then scattering on the GPU
+        grp = f["Q"][str(g)]
+        Q = torch.sparse_coo_tensor(torch.from_numpy(grp["indices"][...].copy()), torch.from_numpy(grp["values"][...].copy()),
+                                    tuple(grp["size"][...].tolist()), dtype=torch.float32).to(dev)
+        xv = torch.from_numpy(c).to(dev).reshape(-1, 1)
+        W = get_Batch_Wjxs(xv, Q, J=2)
+        ref = __import__("oracle.chain_oracle", fromlist=["x"]).ref_get_Batch_Wjxs(xv.cpu(), Q.cpu(), J=2)
+        assert (W.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    f.close()
