@@ -155,21 +155,23 @@ k_csr_step(const int *__restrict__ rowptr, const int *__restrict__ col, const fl
 // backward -> v = sum of gathered G (the Horner start, or the whole answer when T == 0).
 template <int MODE>
 __global__ void __launch_bounds__(256)
-k_events_only(float *v, int ldv, int64_t n, int C, StepEv ev, float *OUT, int64_t ld_row, int F)
+k_events_only(float *v, int ldv, int64_t n, int C, StepEv ev, float *OUT, int64_t ld_row, int F, int pad3)
 {
+    // pad3: v is a float4-per-node vector (scalar row r lives at (r/3)*4 + r%3); only used with C == 1
     const int64_t total = n * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / C; const int c = (int)(i % C);
         float *o = OUT + row * ld_row + (int64_t)c * F;
+        const int64_t va = pad3 ? (row / 3) * 4 + row % 3 : row * ldv + c;
         if (MODE == 1) {
-            const float y = v[row * ldv + c];
+            const float y = v[va];
             for (int k = 0; k < ev.n; ++k)
                 if (ev.e[k].chan < 0 || ev.e[k].chan == c) emit_one(o, y, ev.e[k].slot, ev.e[k].sign);
         } else {
             float y = 0.f;
             for (int k = 0; k < ev.n; ++k)
                 if (ev.e[k].chan < 0 || ev.e[k].chan == c) y += (ev.e[k].sign & 2) ? -o[ev.e[k].slot] : o[ev.e[k].slot];
-            v[row * ldv + c] = y;
+            v[va] = y;
         }
     }
 }
@@ -215,6 +217,64 @@ k_bsr3_step(const int *__restrict__ rowptr, const int *__restrict__ col, const f
                 float *o = OUT + r * F;
                 for (int q = 0; q < ev.n; ++q) emit_one(o, y, ev.e[q].slot, ev.e[q].sign);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ multi-launch path on a packed operator (large graphs)
+// "SELL-64, global columns": rows sorted by length inside windows of a few thousand rows and cut into slices of 64;
+// slice values slot-major exactly as in the per-part pack (escat_sell), one 32-bit GLOBAL block column per slot
+// (-1 = padding), perm = global block row served by each lane.  One wave owns one slice: all of its value/column
+// loads are independent, fully coalesced 1-KiB / 256-B accesses (the CSR kernels above chain rowptr -> col -> x and
+// are latency-bound), the only dependent access is the x gather.  Intermediate vectors are float4 per node so that a
+// gather is one aligned 16-B load.
+struct SellG { const float *val; const int *col32; const int *perm; const int *slice_doff; };
+
+template <int MODE, bool XIN_PACKED, bool YOUT_PACKED>
+__global__ void __launch_bounds__(256)
+k_bsr3_step_sell(SellG sg, int n_slices, const float *__restrict__ xin, float *__restrict__ yout,
+                 StepEv ev, float *OUT, int F)
+{
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const int doff = sg.slice_doff[s];
+    const int w = __builtin_amdgcn_readfirstlane(sg.slice_doff[s + 1] - doff);
+    const int row = sg.perm[(int64_t)s * 64 + lane];
+    const float *vb = sg.val + (int64_t)doff * 576;
+    const int *cb = sg.col32 + (int64_t)doff * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    auto slot = [&](int d) {
+        const int c = cb[(int64_t)d * 64];
+        const float4 p0 = *reinterpret_cast<const float4 *>(vb + (int64_t)d * 576 + lane * 4);
+        const float4 p1 = *reinterpret_cast<const float4 *>(vb + (int64_t)d * 576 + 256 + lane * 4);
+        const float p2 = vb[(int64_t)d * 576 + 512 + lane];
+        if (c >= 0) {
+            float x0, x1, x2;
+            if (XIN_PACKED) { const float *x = xin + (int64_t)c * 3; x0 = x[0]; x1 = x[1]; x2 = x[2]; }
+            else { const float4 xv = *reinterpret_cast<const float4 *>(xin + (int64_t)c * 4); x0 = xv.x; x1 = xv.y; x2 = xv.z; }
+            a0 = fmaf(p0.x, x0, a0); a0 = fmaf(p0.y, x1, a0); a0 = fmaf(p0.z, x2, a0);
+            a1 = fmaf(p0.w, x0, a1); a1 = fmaf(p1.x, x1, a1); a1 = fmaf(p1.y, x2, a1);
+            a2 = fmaf(p1.z, x0, a2); a2 = fmaf(p1.w, x1, a2); a2 = fmaf(p2, x2, a2);
+        }
+    };
+    int d = 0;
+    for (; d + 4 <= w; d += 4) { slot(d); slot(d + 1); slot(d + 2); slot(d + 3); }
+    for (; d < w; ++d) slot(d);
+    if (row < 0) return;
+    float y[3] = {a0, a1, a2};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int64_t r = 3 * (int64_t)row + a;
+        float v = y[a];
+        if (MODE == 2) {
+            const float *gg = OUT + r * F;
+            for (int q = 0; q < ev.n; ++q) v += (ev.e[q].sign & 2) ? -gg[ev.e[q].slot] : gg[ev.e[q].slot];
+        }
+        if (YOUT_PACKED) yout[r] = v; else yout[(int64_t)row * 4 + a] = v;
+        if (MODE == 1) {
+            float *o = OUT + r * F;
+            for (int q = 0; q < ev.n; ++q) emit_one(o, v, ev.e[q].slot, ev.e[q].sign);
         }
     }
 }
@@ -845,7 +905,8 @@ extern "C" size_t escat_chain_workspace_bytes(int64_t n_rows, int C)
 {
     if (n_rows < 0 || C < 1) return 0;
     const int cc = C < ESCAT_MAX_CHANNELS ? C : ESCAT_MAX_CHANNELS;
-    return (size_t)2 * (size_t)n_rows * (size_t)cc * sizeof(float);
+    // + 1/3 for the float4-per-node vectors of the packed BSR-3 path, + alignment slack
+    return (size_t)2 * (size_t)n_rows * (size_t)cc * sizeof(float) * 4 / 3 + 64;
 }
 
 #define LDS_BUDGET (160 * 1024)
@@ -887,12 +948,13 @@ static int launch_chain_csr(int C, int G, const int *rp, const int *ci, const fl
 // ---- register-resident launchers
 static int chain_path_override()
 {
-    // debugging / A-B aid: ESCAT_CHAIN_PATH = reg | stream | multi forces a path (default: best that fits)
+    // debugging / A-B aid: ESCAT_CHAIN_PATH = reg | stream | multi | multi_packed forces a path (default: best that fits)
     const char *e = getenv("ESCAT_CHAIN_PATH");
     if (!e) return 0;
     if (!strcmp(e, "reg")) return 1;
     if (!strcmp(e, "stream")) return 2;
     if (!strcmp(e, "multi")) return 3;
+    if (!strcmp(e, "multi_unpacked") || !strcmp(e, "multi_packed")) return 3;
     return 0;
 }
 
@@ -984,7 +1046,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
     const int G = pick_G(n, nnz);
 
     const int force = chain_path_override();
-    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force != 3) {
+    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3) {
         const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
         if (lds <= LDS_BUDGET) {
             const int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
@@ -1011,7 +1073,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
     if (!BWD) {
         rc = step_events(tab, 0, &se); if (rc) return rc;
         if (se.n) hipLaunchKernelGGL((k_events_only<1>), dim3(grid_for(n * C, 256)), dim3(256), 0, st,
-                                     const_cast<float *>(IN), C, n, C, se, RES, ld_row, F);
+                                     const_cast<float *>(IN), C, n, C, se, RES, ld_row, F, 0);
         const float *xin = IN;
         for (int t = 1; t <= T; ++t) {
             rc = step_events(tab, t, &se); if (rc) return rc;
@@ -1023,7 +1085,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
         float *Gm = const_cast<float *>(IN);
         rc = step_events(tab, T, &se); if (rc) return rc;
         float *acc = T == 0 ? RES : wa;
-        hipLaunchKernelGGL((k_events_only<2>), dim3(grid_for(n * C, 256)), dim3(256), 0, st, acc, C, n, C, se, Gm, ld_row, F);
+        hipLaunchKernelGGL((k_events_only<2>), dim3(grid_for(n * C, 256)), dim3(256), 0, st, acc, C, n, C, se, Gm, ld_row, F, 0);
         const float *xin = acc;
         for (int t = T; t >= 1; --t) {
             rc = step_events(tab, t - 1, &se); if (rc) return rc;
@@ -1073,7 +1135,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
     const int64_t n = 3 * nb;
 
     const int force = chain_path_override();
-    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force != 3) {
+    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3) {
         const size_t lds = (size_t)max_part_rows * 3 * (2 + F) * sizeof(float);
         const size_t lds_s = (2 * ((size_t)max_part_rows + 1) * 4 + (size_t)max_part_rows * 3 * F) * sizeof(float);
         if (lds <= LDS_BUDGET && lds_s <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
@@ -1094,6 +1156,46 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
             return ESCAT_OK;
         }
     }
+    if (sell && sell->col32 && T > 0) {
+        // packed multi-launch path: float4-per-node intermediate vectors
+        if (!sell->val || !sell->perm || !sell->slice_doff) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
+        if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
+        const size_t needp = (size_t)2 * nb * 4 * sizeof(float);
+        if (!workspace || workspace_bytes < needp || ((uintptr_t)workspace & 15) != 0)
+            return fail(ESCAT_EWORKSPACE, "workspace %zu B < %zu B needed (16-byte aligned)", workspace_bytes, needp);
+        SellG sg = {sell->val, sell->col32, sell->perm, sell->slice_doff};
+        const int ns = sell->n_slices;
+        const dim3 grid((ns + 3) / 4), blk256(256);
+        float *pa = (float *)workspace, *pb = pa + nb * 4;
+        StepEv se;
+        if (!BWD) {
+            rc = step_events(tab, 0, &se); if (rc) return rc;
+            if (se.n) hipLaunchKernelGGL((k_events_only<1>), dim3(grid_for(n, 256)), dim3(256), 0, st,
+                                         const_cast<float *>(IN), 1, n, 1, se, RES, (int64_t)F, F, 0);
+            const float *xin = IN;
+            for (int t = 1; t <= T; ++t) {
+                rc = step_events(tab, t, &se); if (rc) return rc;
+                float *y = (t & 1) ? pa : pb;
+                if (t == 1) hipLaunchKernelGGL((k_bsr3_step_sell<1, true, false>), grid, blk256, 0, st, sg, ns, xin, y, se, RES, F);
+                else        hipLaunchKernelGGL((k_bsr3_step_sell<1, false, false>), grid, blk256, 0, st, sg, ns, xin, y, se, RES, F);
+                xin = y;
+            }
+        } else {
+            float *Gm = const_cast<float *>(IN);
+            rc = step_events(tab, T, &se); if (rc) return rc;
+            hipLaunchKernelGGL((k_events_only<2>), dim3(grid_for(n, 256)), dim3(256), 0, st, pa, 1, n, 1, se, Gm, (int64_t)F, F, 1);
+            const float *xin = pa;
+            for (int t = T; t >= 1; --t) {
+                rc = step_events(tab, t - 1, &se); if (rc) return rc;
+                float *y = (t == 1) ? RES : (((T - t) & 1) ? pa : pb);
+                if (t == 1) hipLaunchKernelGGL((k_bsr3_step_sell<2, false, true>), grid, blk256, 0, st, sg, ns, xin, y, se, Gm, F);
+                else        hipLaunchKernelGGL((k_bsr3_step_sell<2, false, false>), grid, blk256, 0, st, sg, ns, xin, y, se, Gm, F);
+                xin = y;
+            }
+        }
+        CHECK_LAUNCH("k_bsr3_step_sell chain");
+        return ESCAT_OK;
+    }
     const size_t need = (size_t)2 * n * sizeof(float);
     if (T > 0 && (!workspace || workspace_bytes < need))
         return fail(ESCAT_EWORKSPACE, "workspace %zu B < %zu B needed", workspace_bytes, need);
@@ -1102,7 +1204,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
     if (!BWD) {
         rc = step_events(tab, 0, &se); if (rc) return rc;
         if (se.n) hipLaunchKernelGGL((k_events_only<1>), dim3(grid_for(n, 256)), dim3(256), 0, st,
-                                     const_cast<float *>(IN), 1, n, 1, se, RES, (int64_t)F, F);
+                                     const_cast<float *>(IN), 1, n, 1, se, RES, (int64_t)F, F, 0);
         const float *xin = IN;
         for (int t = 1; t <= T; ++t) {
             rc = step_events(tab, t, &se); if (rc) return rc;
@@ -1114,7 +1216,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
         float *Gm = const_cast<float *>(IN);
         rc = step_events(tab, T, &se); if (rc) return rc;
         float *acc = T == 0 ? RES : wa;
-        hipLaunchKernelGGL((k_events_only<2>), dim3(grid_for(n, 256)), dim3(256), 0, st, acc, 1, n, 1, se, Gm, (int64_t)F, F);
+        hipLaunchKernelGGL((k_events_only<2>), dim3(grid_for(n, 256)), dim3(256), 0, st, acc, 1, n, 1, se, Gm, (int64_t)F, F, 0);
         const float *xin = acc;
         for (int t = T; t >= 1; --t) {
             rc = step_events(tab, t - 1, &se); if (rc) return rc;

@@ -159,8 +159,49 @@ class Sell:
         self.pad_ratio = float(total_d * 64) / max(float(dcl.sum()), 1.0)
 
 
+class SellGlobal:
+    """
+    SELL-64 pack of a whole BSR-3 operator with GLOBAL columns (escat_sell.col32) for the multi-launch path of graphs
+    that do not fit LDS: rows sorted by length inside windows of `window` rows, slices of 64, no length cap.
+    """
+
+    def __init__(self, form, window: int = 2048):
+        assert form.val.dim() == 3 and window % 64 == 0
+        dev = form.rowptr.device
+        n, nnz = form.n, form.nnz
+        rp = form.rowptr.long()
+        deg = rp[1:] - rp[:-1]
+        maxdeg = int(deg.max()) if n else 0
+        order = torch.argsort((torch.arange(n, device=dev) // window) * (maxdeg + 1) + (maxdeg - deg), stable=True)
+        n_slices = (n + 63) // 64
+        perm = torch.full((n_slices * 64,), -1, dtype=torch.int32, device=dev)
+        perm[:n] = order.to(torch.int32)
+        slot_deg = torch.zeros(n_slices * 64, dtype=torch.int64, device=dev)
+        slot_deg[:n] = deg[order]
+        w = slot_deg.view(n_slices, 64).max(dim=1).values
+        doff = _cumsum0(w)
+        total_d = int(doff[-1])
+        row_slot = torch.empty(n, dtype=torch.int64, device=dev)
+        row_slot[order] = torch.arange(n, device=dev)
+        row_of_e = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+        d_of_e = torch.arange(nnz, device=dev) - rp[row_of_e]
+        sl = row_slot[row_of_e]
+        drow = doff[sl // 64] + d_of_e
+        lane = sl % 64
+        val = torch.zeros(max(total_d, 1) * 576, dtype=torch.float32, device=dev)
+        src = form.val.reshape(nnz, 9)
+        for q in range(9):
+            val[drow * 576 + (q // 4) * 256 + (lane * 4 + q % 4 if q < 8 else lane)] = src[:, q]
+        col32 = torch.full((max(total_d, 1) * 64,), -1, dtype=torch.int32, device=dev)
+        col32[drow * 64 + lane] = form.col
+        self.val, self.col32, self.perm = val, col32, perm
+        self.slice_doff = doff.to(torch.int32)
+        self.n_slices = n_slices
+        self.pad_ratio = float(total_d * 64) / max(float(nnz), 1.0)
+
+
 class _Csr:
-    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "max_row_nnz", "_sell")
+    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "max_row_nnz", "_sell", "_sell_g")
 
     def __init__(self, rowptr, col, val, n, parts=None):
         self.rowptr, self.col, self.val, self.n = rowptr, col, val, n
@@ -170,6 +211,13 @@ class _Csr:
         self.part_ptr, self.n_parts, self.max_part_rows = parts
         self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) if n > 0 else 0
         self._sell = None
+        self._sell_g = None
+
+    def sell_global(self):
+        """whole-operator pack with global columns for the multi-launch path (BSR-3 only)."""
+        if self._sell_g is None and self.val.dim() == 3 and self.nnz > 0:
+            self._sell_g = SellGlobal(self)
+        return self._sell_g
 
     def sell(self):
         """packed SELL-64 copy for the register-resident kernels (None if the parts are too large)."""

@@ -47,19 +47,28 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
     rows_per = 3 if use_bsr else 1
     out = torch.empty((n, C) if backward else (n, C, F), dtype=torch.float32, device=dev)
     lds = form.max_part_rows * rows_per * C * (2 + F) * 4
-    fused = form.n_parts > 0 and lds <= LDS_BUDGET and os.environ.get("ESCAT_CHAIN_PATH") != "multi"
+    path = os.environ.get("ESCAT_CHAIN_PATH", "")
+    fused = form.n_parts > 0 and lds <= LDS_BUDGET and not path.startswith("multi")
     ws = None
     if not fused and T > 0:
         ws = torch.empty(lib.escat_chain_workspace_bytes(n, C) // 4, dtype=torch.float32, device=dev)
     ws_bytes = ws.numel() * 4 if ws is not None else 0
     sell = form.sell() if fused else None
-    if sell is not None and (form.max_part_rows * rows_per * C > 0xffff or os.environ.get("ESCAT_CHAIN_PATH") == "stream"):
+    if sell is not None and (form.max_part_rows * rows_per * C > 0xffff or path == "stream"):
         sell = None
     sell_ref = ctypes.c_void_p(0)
     if sell is not None:
         sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.perm.data_ptr(),
                                      sell.slice_doff.data_ptr(), sell.slice_poff.data_ptr(),
-                                     sell.part_slice_ptr.data_ptr(), sell.dmax, sell.n_slices)
+                                     sell.part_slice_ptr.data_ptr(), sell.dmax, sell.n_slices, 0)
+        sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
+    elif not fused and use_bsr and T > 0 and path == "multi_packed":
+        # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
+        # cfg3 it does not beat the lane-group step kernel (0.61 vs 0.53 ms/step on a locality-sorted cloud, equal on
+        # random node order where the x gather dominates), so the default multi-launch path stays unpacked.
+        sg = form.sell_global()
+        sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0,
+                                     sg.n_slices, sg.col32.data_ptr())
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)

@@ -82,6 +82,10 @@ typedef struct {
     const int32_t  *part_slice_ptr;
     int32_t         dmax;
     int32_t         n_slices;
+    const int32_t  *col32;          /* NULL, or: one GLOBAL (block) column per slot, [(doff_s + d)*64 + lane], -1 = padding.
+                                       Then the pack covers the whole operator (slices of 64 rows sorted by length inside
+                                       windows, perm = global row, lc / slice_poff / part_slice_ptr unused, no dmax cap)
+                                       and drives the multi-launch path for graphs that do not fit LDS (BSR-3 only). */
 } escat_sell;
 
 /* last error message of the calling thread ("" if none). */

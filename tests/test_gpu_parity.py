@@ -229,7 +229,7 @@ def test_all_three_chain_paths_agree(monkeypatch):
         refgP = co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T)
         refgQ = co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T)
         outs = {}
-        for path in ("reg", "stream", "multi"):
+        for path in ("reg", "stream", "multi", "multi_packed"):
             monkeypatch.setenv("ESCAT_CHAIN_PATH", path)
             xg = x.to(dev).requires_grad_(True)
             W = get_Batch_Wjxs(xg, opP, **kw)
