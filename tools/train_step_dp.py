@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""BASELINE cfg4: full ESc-GNN-style training step, data-parallel over GPUs (one process per GPU, RCCL all-reduce of
+one flat gradient bucket).  Operators are built on the GPU (build_PQ_batch), scattering runs through libescat.so.
+  python tools/train_step_dp.py --steps 20                          (1 GPU)
+  python -m torch.distributed.run --nproc-per-node N tools/train_step_dp.py --gpus N ...
+Prints one JSON line on rank 0: graphs/s (all ranks), ms/step, parameter count."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--graphs", type=int, default=4096, help="graphs per GPU per step")
+    ap.add_argument("--nodes", type=int, default=128)
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    import numpy as np, torch, torch.distributed as dist
+    from esc_gnn_amd import synthetic
+    from esc_gnn_amd.dist_utils import env_rank_world, max_over_ranks
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    from esc_gnn_amd.train_dp import DPTrainer
+    rank, local_rank, world = env_rank_world()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    clouds = synthetic.ellipsoid_clouds(args.graphs, args.nodes, seed=457892 + rank)
+    pos = torch.from_numpy(clouds.reshape(-1, 3)).to(dev)
+    gp = torch.arange(args.graphs + 1, dtype=torch.int32, device=dev) * args.nodes
+    b = build_PQ_batch(pos, gp, args.k, {"kernel": "gaussian", "gaussian_eps": 0.05}, max_graph_nodes=args.nodes)
+    graph_id = torch.arange(args.graphs, device=dev).repeat_interleave(args.nodes)
+    # synthetic graph-level target: the cloud's diameter-like extent (max coordinate range)
+    target = torch.from_numpy((clouds.max(1) - clouds.min(1)).max(1).astype(np.float32)).to(dev)
+    torch.manual_seed(0)          # identical initial weights on every rank
+    tr = DPTrainer(C=3, diffusion_kwargs=dict(scales_type="dyadic", J=4, include_lowpass=True), device=dev)
+    b["P"].csr().sell(); b["Q"].bsr3().sell()
+    losses = []
+    for _ in range(args.warmup):
+        tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target)
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target))
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({"workload": f"cfg4: DP training step, {args.graphs} graphs x {args.nodes} nodes per GPU, k={args.k}, J=4",
+                          "n_gpus": world, "graphs_per_s": args.graphs * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                          "params": tr.n_params(), "loss_first": float(losses[0]), "loss_last": float(losses[-1])}))
+    if world > 1: dist.destroy_process_group()
+
+if __name__ == "__main__":
+    main()
