@@ -27,7 +27,8 @@ class EscatEvent(ctypes.Structure):
 class EscatSell(ctypes.Structure):
     _fields_ = [("val", ctypes.c_void_p), ("lc", ctypes.c_void_p), ("perm", ctypes.c_void_p),
                 ("slice_doff", ctypes.c_void_p), ("slice_poff", ctypes.c_void_p), ("part_slice_ptr", ctypes.c_void_p),
-                ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("col32", ctypes.c_void_p)]
+                ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("lanes_per_row", ctypes.c_int32),
+                ("col32", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/escat.h declares

@@ -577,16 +577,20 @@ struct SellDev {
 
 #define SLOT_GROUP 4      // slots issued together: their LDS gathers are in flight at once
 
-template <int DMAX, int NT, bool BWD>
+// LPR = lanes per row.  LPR = 1: one thread per block row, up to 22 blocks in 256 VGPRs (one 512-thread or two
+// 256-thread workgroups per CU).  LPR = 2: lanes 2i and 2i+1 share row i (even / odd entries, <= 12 blocks each in
+// <= 128 VGPRs), combined with one DPP-class shuffle per step: a 1024-thread workgroup covers 512 rows and TWO
+// workgroups fit a CU, so one graph's operator load overlaps the other graph's T steps.
+template <int DMAX, int NT, bool BWD, int LPR>
 __global__ void __launch_bounds__(NT)
 k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
                   const int *__restrict__ part_ptr, SellDev sd, const float *__restrict__ X, float *__restrict__ OUT,
                   int T, EvTable tab, int F)
 {
-    static_assert(DMAX % 2 == 0, "DMAX must be even (packed column offsets)");
+    constexpr int GRP = LPR == 2 ? 1 : SLOT_GROUP;
     extern __shared__ __align__(16) float smem[];
     const int gs = part_ptr[blockIdx.x], brows = part_ptr[blockIdx.x + 1] - gs;
-    if (brows > NT) return;                       // host guarantees max_part_rows <= NT
+    if (brows * LPR > NT) return;                 // host guarantees max_part_rows * LPR <= NT
     const int nv = (brows + 1) * 4;               // padded vector: float4 per node + the zero node
     float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -594,15 +598,15 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
     const unsigned zoff = (unsigned)brows * 4u;
 
     float b[DMAX * 9];
-    unsigned lc[DMAX / 2];
+    unsigned lc[(DMAX + 1) / 2];
     int r = -1, e0 = 0, deg = 0, w = 0;
 #pragma unroll
     for (int q = 0; q < DMAX * 9; ++q) b[q] = 0.f;
 #pragma unroll
-    for (int q = 0; q < DMAX / 2; ++q) lc[q] = zoff | (zoff << 16);
+    for (int q = 0; q < (DMAX + 1) / 2; ++q) lc[q] = zoff | (zoff << 16);
     if (wave < ns) {
-        const int s = s0 + wave;
-        const int doff = sd.slice_doff[s], poff = sd.slice_poff[s];
+        const int s = __builtin_amdgcn_readfirstlane(s0 + wave);
+        const int doff = __builtin_amdgcn_readfirstlane(sd.slice_doff[s]), poff = __builtin_amdgcn_readfirstlane(sd.slice_poff[s]);
         w = __builtin_amdgcn_readfirstlane(sd.slice_doff[s + 1] - doff);
         r = sd.perm[s * 64 + lane];
         if (r >= 0) { e0 = rowptr[gs + r]; deg = rowptr[gs + r + 1] - e0; }
@@ -619,14 +623,14 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
             }
         }
 #pragma unroll
-        for (int j2 = 0; j2 < DMAX / 2; ++j2) {
+        for (int j2 = 0; j2 < (DMAX + 1) / 2; ++j2) {
             if (2 * j2 < w) {
                 const unsigned v = sd.lc[(int64_t)(poff + j2) * 64 + lane];
                 lc[j2] = ((v & 0xffffu) * 4u) | (((v >> 16) * 4u) << 16);      // float offsets into the LDS vector
             }
         }
     }
-    const bool own = r >= 0;
+    const bool own = r >= 0 && (LPR == 1 || (lane & 1) == 0);
 
     int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, brows, 3, 4, F, T, tab);
     for (int t = 1; t <= T; ++t) {
@@ -634,11 +638,11 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
         step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
+        for (int d0 = 0; d0 < DMAX; d0 += GRP) {
             if (d0 < w) {                         // wave-uniform: slice width, in groups
-                float4 xv[SLOT_GROUP];
+                float4 xv[GRP];
 #pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
+                for (int g = 0; g < GRP; ++g) {
                     const int d = d0 + g;
                     if (d < DMAX) {
                         const unsigned off = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
@@ -646,7 +650,7 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
+                for (int g = 0; g < GRP; ++g) {
                     const int d = d0 + g;
                     if (d < DMAX) {
                         const float x0 = xv[g].x, x1 = xv[g].y, x2 = xv[g].z;
@@ -657,8 +661,9 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
                 }
             }
         }
-        if (own) {
-            for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {   // rows longer than the pack: tail from L2
+        if (r >= 0) {
+            // rows longer than the pack: tail from L2 (lane h of a row takes entries dmax*LPR + h, + LPR, ...)
+            for (int e = e0 + sd.dmax * LPR + (lane & (LPR - 1)); e < e0 + deg; e += LPR) {
                 const float *bb = blk + (int64_t)e * 9;
                 const float *x = xa + (col[e] - gs) * 4;
                 const float x0 = x[0], x1 = x[1], x2 = x[2];
@@ -666,6 +671,9 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
                 a1 = fmaf(bb[3], x0, a1); a1 = fmaf(bb[4], x1, a1); a1 = fmaf(bb[5], x2, a1);
                 a2 = fmaf(bb[6], x0, a2); a2 = fmaf(bb[7], x1, a2); a2 = fmaf(bb[8], x2, a2);
             }
+        }
+        if (LPR == 2) { a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64); }
+        if (own) {
             float *o = slab + 3 * r * F;
             xb[4 * r + 0] = apply_events<BWD>(tab, q0, q1, 0, a0, o);
             xb[4 * r + 1] = apply_events<BWD>(tab, q0, q1, 0, a1, o + F);
@@ -969,6 +977,7 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
     if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
     sd->val = sell->val; sd->lc = sell->lc; sd->perm = sell->perm; sd->slice_doff = sell->slice_doff;
     sd->slice_poff = sell->slice_poff; sd->part_slice_ptr = sell->part_slice_ptr; sd->dmax = sell->dmax;
+    if (sell->lanes_per_row != 1 && sell->lanes_per_row != 2) return fail(ESCAT_EINVAL, "escat_sell.lanes_per_row must be 1 or 2");
     return ESCAT_OK;
 }
 
@@ -976,15 +985,29 @@ template <int DMAX, bool BWD>
 static int launch_bsr3_sell_d(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
                               const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
-    if (NT <= 256) LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 256, BWD>), 256);
-    else           LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 512, BWD>), 512);
+    if (NT <= 256) LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 256, BWD, 1>), 256);
+    else           LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 512, BWD, 1>), 512);
+    return ESCAT_OK;
+}
+template <int DMAX, bool BWD>
+static int launch_bsr3_sell2_d(const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
+                               const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 1024, BWD, 2>), 1024);
     return ESCAT_OK;
 }
 template <bool BWD>
-static int launch_bsr3_sell(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
+static int launch_bsr3_sell(int lpr, int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
                             size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F,
                             hipStream_t st)
 {
+    if (lpr == 2) {
+        switch (sd.dmax) {
+            case 8:  return launch_bsr3_sell2_d<8, BWD>(rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+            case 11: return launch_bsr3_sell2_d<11, BWD>(rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        }
+        return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: two-lane BSR-3 packs must use 8 or 11", sd.dmax);
+    }
     switch (sd.dmax) {
         case 8:  return launch_bsr3_sell_d<8, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
         case 12: return launch_bsr3_sell_d<12, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
@@ -1055,6 +1078,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
             if (max_part_rows <= 512 && sell && force != 2 && lds_s <= LDS_BUDGET) {
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
+                if (sell->lanes_per_row != 1) return fail(ESCAT_EINVAL, "CSR packs use one lane per row");
                 rc = launch_csr_sell<BWD>(C, max_part_rows, rowptr, col, val, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
             } else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
@@ -1141,7 +1165,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
         if (lds <= LDS_BUDGET && lds_s <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
-            rc = launch_bsr3_sell<BWD>(max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
+            rc = launch_bsr3_sell<BWD>(sell->lanes_per_row, max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_bsr3_sell");
             return ESCAT_OK;

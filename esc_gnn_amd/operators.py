@@ -16,6 +16,7 @@ The sort/unique calls here are torch device ops (plumbing, done once per
 operator and cached on the tensor object); the products themselves never touch
 torch.
 """
+import os
 from typing import Optional
 import numpy as np
 import torch
@@ -83,14 +84,20 @@ class Sell:
     """
     SELL-64 pack of a CSR (val (nnz,)) or BSR-3 (val (nnz,3,3)) operator; layout in
     include/escat.h (escat_sell).  Built with torch index ops on the operator's device.
+    lanes_per_row = 2 (BSR-3): lanes 2i, 2i+1 of a slice share row i; lane h holds entries h, h+2, ... of the row.
     """
 
-    def __init__(self, form):
+    def __init__(self, form, lanes_per_row: int = 1):
         dev = form.rowptr.device
         V = 9 if form.val.dim() == 3 else 1
-        caps = _SELL_DMAX[V]
-        self.dmax = next((c for c in caps if c >= form.max_row_nnz), caps[-1])
+        L = lanes_per_row
+        assert L in (1, 2) and (L == 1 or V == 9)
+        caps = _SELL_DMAX[V] if L == 1 else (8, 11)
+        need = (form.max_row_nnz + L - 1) // L
+        self.dmax = next((c for c in caps if c >= need), caps[-1])
+        self.lanes_per_row = L
         dmax = self.dmax
+        RPS = 64 // L                                   # rows per slice
         n, nnz = form.n, form.nnz
         rp = form.rowptr.long()
         deg = rp[1:] - rp[:-1]
@@ -98,26 +105,30 @@ class Sell:
         n_parts = form.n_parts
         part_rows = pp[1:] - pp[:-1]
         part_of_row = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_rows)
-        dcl = deg.clamp(max=dmax)
-        order = torch.argsort(part_of_row * (dmax + 1) + (dmax - dcl), stable=True)     # rows in slot order
-        part_slices = (part_rows + 63) // 64
+        dcl = deg.clamp(max=dmax * L)
+        order = torch.argsort(part_of_row * (dmax * L + 1) + (dmax * L - dcl), stable=True)     # rows in slot order
+        part_slices = (part_rows + RPS - 1) // RPS
         psp = _cumsum0(part_slices)
         n_slices = int(psp[-1])
-        slot = psp[part_of_row] * 64 + (torch.arange(n, device=dev) - pp[part_of_row])  # sorted position i -> slot
+        # sorted position i (row order[i], part part_of_row[i]) -> first lane of its slot
+        slot0 = psp[part_of_row] * 64 + (torch.arange(n, device=dev) - pp[part_of_row]) * L
         perm = torch.full((n_slices * 64,), -1, dtype=torch.int32, device=dev)
-        perm[slot] = (order - pp[part_of_row]).to(torch.int32)
-        slot_deg = torch.zeros(n_slices * 64, dtype=torch.int64, device=dev)
-        slot_deg[slot] = dcl[order]
-        w = slot_deg.view(n_slices, 64).max(dim=1).values
+        lrow = (order - pp[part_of_row]).to(torch.int32)
+        slot_cnt = torch.zeros(n_slices * 64, dtype=torch.int64, device=dev)
+        for h in range(L):
+            perm[slot0 + h] = lrow
+            slot_cnt[slot0 + h] = (dcl[order] - h + L - 1) // L          # entries h, h+L, ... below the cap
+        w = slot_cnt.view(n_slices, 64).max(dim=1).values
         doff, poff = _cumsum0(w), _cumsum0((w + 1) // 2)
-        row_slot = torch.empty(n, dtype=torch.int64, device=dev)
-        row_slot[order] = slot
+        row_slot0 = torch.empty(n, dtype=torch.int64, device=dev)
+        row_slot0[order] = slot0
         row_of_e = torch.repeat_interleave(torch.arange(n, device=dev), deg)
         d_of_e = torch.arange(nnz, device=dev) - rp[row_of_e]
-        keep = d_of_e < dmax
+        keep = d_of_e < dmax * L
         e_k = torch.nonzero(keep).flatten()
-        r_k, d_k = row_of_e[e_k], d_of_e[e_k]
-        sl = row_slot[r_k]
+        r_k = row_of_e[e_k]
+        d_k = d_of_e[e_k] // L
+        sl = row_slot0[r_k] + d_of_e[e_k] % L
         s_k, lane = sl // 64, sl % 64
         drow = doff[s_k] + d_k
         total_d, total_p = int(doff[-1]), int(poff[-1])
@@ -222,7 +233,14 @@ class _Csr:
     def sell(self):
         """packed SELL-64 copy for the register-resident kernels (None if the parts are too large)."""
         if self._sell is None and 0 < self.max_part_rows <= SELL_MAX_PART_ROWS and self.nnz > 0:
-            self._sell = Sell(self)
+            # opt-in experiment (ESCAT_SELL_LPR=2): two lanes per row for BSR-3 parts of more than 256 rows, so that a
+            # 1024-thread workgroup needs <= 128 VGPRs and two workgroups share a CU (one loading, one stepping).
+            # Measured on cfg2 it LOSES (Q chain 1.19 ms vs 0.73 ms): the per-lane capacity of 11 blocks spills 21
+            # VGPRs that are reloaded every step, and with half the slots per lane the LDS gathers are no longer
+            # batched.  Kept for the record and for tests; default is one lane per row.
+            two = self.val.dim() == 3 and self.max_part_rows > 256 and self.max_row_nnz <= 22 \
+                and os.environ.get("ESCAT_SELL_LPR", "1") == "2"
+            self._sell = Sell(self, 2 if two else 1)
         return self._sell
 
 

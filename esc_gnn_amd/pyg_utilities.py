@@ -60,7 +60,7 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
     if sell is not None:
         sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.perm.data_ptr(),
                                      sell.slice_doff.data_ptr(), sell.slice_poff.data_ptr(),
-                                     sell.part_slice_ptr.data_ptr(), sell.dmax, sell.n_slices, 0)
+                                     sell.part_slice_ptr.data_ptr(), sell.dmax, sell.n_slices, sell.lanes_per_row, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
@@ -68,7 +68,7 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
         # random node order where the x gather dominates), so the default multi-launch path stays unpacked.
         sg = form.sell_global()
         sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0,
-                                     sg.n_slices, sg.col32.data_ptr())
+                                     sg.n_slices, 1, sg.col32.data_ptr())
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)

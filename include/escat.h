@@ -82,6 +82,8 @@ typedef struct {
     const int32_t  *part_slice_ptr;
     int32_t         dmax;
     int32_t         n_slices;
+    int32_t         lanes_per_row;  /* 1, or 2 (BSR-3 only): lanes 2i, 2i+1 of a slice share row i (32 rows per slice), lane h
+                                       holds entries h, h+2, ... of the row (dmax = per-lane capacity: 8 or 11) */
     const int32_t  *col32;          /* NULL, or: one GLOBAL (block) column per slot, [(doff_s + d)*64 + lane], -1 = padding.
                                        Then the pack covers the whole operator (slices of 64 rows sorted by length inside
                                        windows, perm = global row, lc / slice_poff / part_slice_ptr unused, no dmax cap)

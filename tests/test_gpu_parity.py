@@ -246,6 +246,26 @@ def test_all_three_chain_paths_agree(monkeypatch):
     monkeypatch.delenv("ESCAT_CHAIN_PATH")
 
 
+def test_two_lanes_per_row_pack(monkeypatch):
+    """opt-in pack variant (ESCAT_SELL_LPR=2: lanes 2i, 2i+1 share a row) gives the same answers."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    dev = _dev()
+    monkeypatch.setenv("ESCAT_SELL_LPR", "2")
+    b = synthetic.ellipsoid_batch(3, 400, 10, seed=21)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    assert opQ.bsr3().sell().lanes_per_row == 2
+    plan = plan_chain(J=4)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    xg = xv.to(dev).requires_grad_(True)
+    W = get_Batch_Wjxs(xg, opQ, J=4)
+    _close(W, co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F))
+    g = torch.randn(W.shape, generator=torch.Generator().manual_seed(0))
+    W.backward(g.to(dev))
+    _close(xg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], g.numpy(), ev, plan.T), rtol=2e-5)
+
+
 def test_register_path_long_rows_and_small_parts():
     """rows longer than the register capacity (DMAX) take the streamed tail; parts of many tiny graphs."""
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
