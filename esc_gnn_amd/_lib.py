@@ -27,7 +27,7 @@ class EscatEvent(ctypes.Structure):
 class EscatSell(ctypes.Structure):
     _fields_ = [("val", ctypes.c_void_p), ("lc", ctypes.c_void_p), ("perm", ctypes.c_void_p),
                 ("slice_doff", ctypes.c_void_p), ("slice_poff", ctypes.c_void_p), ("part_slice_ptr", ctypes.c_void_p),
-                ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("lanes_per_row", ctypes.c_int32),
+                ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("col32", ctypes.c_void_p)]
 
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_scatter_orders_f32": (ci, [vp, vp, i64, ci, ci, vp, vp]),
     "escat_scatter_orders_bwd_f32": (ci, [vp, vp, i64, ci, ci, vp, vp, vp]),
+    "escat_sell_plan_slots": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]),
     "escat_build_workspace_bytes": (sz, [i64, ci, ci]),
     "escat_build_knn_P": (ci, [vp, vp, ci, i64, ci, ci, vp, vp, vp, i64, vp, vp, sz, vp]),
     "escat_build_frames": (ci, [vp, vp, vp, i64, ci, ctypes.c_float, ci, ctypes.c_float, ci, ci, ci, vp, vp, vp]),

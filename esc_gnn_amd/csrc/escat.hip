@@ -480,15 +480,30 @@ __device__ __forceinline__ int wave_max_i(int v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-// LDS vectors of these kernels are padded: row r, channel c lives at r*CP + c with
-// CP = C rounded up to 1/2/4/8 floats, so that a gather is one aligned ds_read_b32/
-// b64/b128; one extra all-zero row at index `rows` is the target of padded slots.
-//
+// LDS vectors of these kernels are padded and kept in TWO copies: row r, channel c lives at r*CP + c (copy A) and
+// at (R + copyB(r))*CP + c (copy B), CP = C rounded up to 1/2/4/8 floats so that a gather is one aligned
+// ds_read_b32/b64/b128, R = rows + 1 rounded up to 16.  Copy B permutes the rows (bits 0-3 of the index rotate to the
+// top of a 256-row block), so a row's 16-byte bank slot is (r & 15) in copy A and ((r >> 4) & 15) in copy B.  At pack
+// time every gather is given the copy -- and every row's entries the slot order -- that keeps the 16 lanes of a
+// ds_read_b128 lane group on distinct bank slots (k_sell_plan below); this cuts the measured LDS bank-conflict cycles
+// of the random gather, the bound of the step loop.  One all-zero row (index `rows`, copy A) is the target of padded slots.
+__host__ __device__ __forceinline__ int sell_padR(int rows) { return (rows + 1 + 15) & ~15; }
+__host__ __device__ __forceinline__ int sell_copyB(int p, int R)
+{
+    int m = 8;
+    if (R < 256) { m = 0; while ((2 << m) <= R) ++m; }       // floor(log2(R))
+    if (m < 5) return p;
+    const int blk = 1 << m, lim = (R >> m) << m;
+    if (p >= lim) return p;
+    const int lo = p & (blk - 1);
+    return (p & ~(blk - 1)) | (lo >> 4) | ((lo & 15) << (m - 4));
+}
+
 // loads x (fwd) or the upstream-gradient slab (bwd) of a part into LDS, applies the
 // step-0 events (fwd) / forms the Horner start (bwd); returns the event cursor.
 template <bool BWD, int NT>
 __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab, const float *__restrict__ IN,
-                                              int64_t first_row, int rows, int C, int CP, int F, int T, const EvTable &tab)
+                                              int64_t first_row, int rows, int R, int C, int CP, int F, int T, const EvTable &tab)
 {
     const int tid = threadIdx.x;
     const int nc = rows * C;
@@ -498,8 +513,9 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab,
         const float *xg = IN + first_row * C;
         int p1 = 0; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
         for (int i = tid; i < nc; i += NT) {
-            const int c = i % C; const float y = xg[i];
-            xa[(i / C) * CP + c] = y;
+            const int c = i % C, r = i / C; const float y = xg[i];
+            xa[r * CP + c] = y;
+            xa[(R + sell_copyB(r, R)) * CP + c] = y;
             for (int k = 0; k < p1; ++k)
                 if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * F, y, tab.e[k].slot, tab.e[k].sign);
         }
@@ -510,10 +526,11 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab,
         __syncthreads();
         int p0 = tab.n; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
         for (int i = tid; i < nc; i += NT) {
-            const int c = i % C; float y = 0.f;
+            const int c = i % C, r = i / C; float y = 0.f;
             for (int k = p0; k < tab.n; ++k)
                 if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -slab[i * F + tab.e[k].slot] : slab[i * F + tab.e[k].slot];
-            xa[(i / C) * CP + c] = y;
+            xa[r * CP + c] = y;
+            xa[(R + sell_copyB(r, R)) * CP + c] = y;
         }
         p = p0;
     }
@@ -577,21 +594,18 @@ struct SellDev {
 
 #define SLOT_GROUP 4      // slots issued together: their LDS gathers are in flight at once
 
-// LPR = lanes per row.  LPR = 1: one thread per block row, up to 22 blocks in 256 VGPRs (one 512-thread or two
-// 256-thread workgroups per CU).  LPR = 2: lanes 2i and 2i+1 share row i (even / odd entries, <= 12 blocks each in
-// <= 128 VGPRs), combined with one DPP-class shuffle per step: a 1024-thread workgroup covers 512 rows and TWO
-// workgroups fit a CU, so one graph's operator load overlaps the other graph's T steps.
-template <int DMAX, int NT, bool BWD, int LPR>
+template <int DMAX, int NT, bool BWD>
 __global__ void __launch_bounds__(NT)
 k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
                   const int *__restrict__ part_ptr, SellDev sd, const float *__restrict__ X, float *__restrict__ OUT,
                   int T, EvTable tab, int F)
 {
-    constexpr int GRP = LPR == 2 ? 1 : SLOT_GROUP;
+    constexpr int GRP = SLOT_GROUP;
     extern __shared__ __align__(16) float smem[];
     const int gs = part_ptr[blockIdx.x], brows = part_ptr[blockIdx.x + 1] - gs;
-    if (brows * LPR > NT) return;                 // host guarantees max_part_rows * LPR <= NT
-    const int nv = (brows + 1) * 4;               // padded vector: float4 per node + the zero node
+    if (brows > NT) return;                       // host guarantees max_part_rows <= NT
+    const int R = sell_padR(brows);
+    const int nv = 2 * R * 4;                     // two copies of a float4-per-node vector (incl. the zero node)
     float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
@@ -630,9 +644,10 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
             }
         }
     }
-    const bool own = r >= 0 && (LPR == 1 || (lane & 1) == 0);
+    const bool own = r >= 0;
+    const int rB = own ? R + sell_copyB(r, R) : 0;
 
-    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, brows, 3, 4, F, T, tab);
+    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, brows, R, 3, 4, F, T, tab);
     for (int t = 1; t <= T; ++t) {
         int q0, q1;
         step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
@@ -657,13 +672,15 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
                         a0 = fmaf(b[9 * d + 0], x0, a0); a0 = fmaf(b[9 * d + 1], x1, a0); a0 = fmaf(b[9 * d + 2], x2, a0);
                         a1 = fmaf(b[9 * d + 3], x0, a1); a1 = fmaf(b[9 * d + 4], x1, a1); a1 = fmaf(b[9 * d + 5], x2, a1);
                         a2 = fmaf(b[9 * d + 6], x0, a2); a2 = fmaf(b[9 * d + 7], x1, a2); a2 = fmaf(b[9 * d + 8], x2, a2);
+                        // keep the pad lane live: otherwise the gather is narrowed to ds_read_b96 (8 LDS cycles, 8-lane
+                        // groups on 32 banks) instead of ds_read_b128 (4 cycles, the 16-lane groups the pack is planned for)
+                        asm volatile("" :: "v"(xv[g].w));
                     }
                 }
             }
         }
-        if (r >= 0) {
-            // rows longer than the pack: tail from L2 (lane h of a row takes entries dmax*LPR + h, + LPR, ...)
-            for (int e = e0 + sd.dmax * LPR + (lane & (LPR - 1)); e < e0 + deg; e += LPR) {
+        if (own) {
+            for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {   // rows longer than the pack: tail from L2
                 const float *bb = blk + (int64_t)e * 9;
                 const float *x = xa + (col[e] - gs) * 4;
                 const float x0 = x[0], x1 = x[1], x2 = x[2];
@@ -671,13 +688,13 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
                 a1 = fmaf(bb[3], x0, a1); a1 = fmaf(bb[4], x1, a1); a1 = fmaf(bb[5], x2, a1);
                 a2 = fmaf(bb[6], x0, a2); a2 = fmaf(bb[7], x1, a2); a2 = fmaf(bb[8], x2, a2);
             }
-        }
-        if (LPR == 2) { a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64); }
-        if (own) {
             float *o = slab + 3 * r * F;
-            xb[4 * r + 0] = apply_events<BWD>(tab, q0, q1, 0, a0, o);
-            xb[4 * r + 1] = apply_events<BWD>(tab, q0, q1, 0, a1, o + F);
-            xb[4 * r + 2] = apply_events<BWD>(tab, q0, q1, 0, a2, o + 2 * F);
+            a0 = apply_events<BWD>(tab, q0, q1, 0, a0, o);
+            a1 = apply_events<BWD>(tab, q0, q1, 0, a1, o + F);
+            a2 = apply_events<BWD>(tab, q0, q1, 0, a2, o + 2 * F);
+            const float4 y = make_float4(a0, a1, a2, 0.f);          // one 16-B store per copy: 32 banks serve 8 lanes
+            *reinterpret_cast<float4 *>(xb + 4 * r) = y;
+            *reinterpret_cast<float4 *>(xb + 4 * rB) = y;
         }
         __syncthreads();
         float *sw = xa; xa = xb; xb = sw;
@@ -686,12 +703,22 @@ k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, c
 }
 
 template <int CP> struct XVec;
-template <> struct XVec<1> { float v[1]; __device__ __forceinline__ void load(const float *p) { v[0] = p[0]; } };
-template <> struct XVec<2> { float v[2]; __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; } };
-template <> struct XVec<4> { float v[4]; __device__ __forceinline__ void load(const float *p) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; } };
-template <> struct XVec<8> { float v[8]; __device__ __forceinline__ void load(const float *p) {
-    const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 4);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; } };
+template <> struct XVec<1> { float v[1];
+    __device__ __forceinline__ void load(const float *p) { v[0] = p[0]; }
+    __device__ __forceinline__ void store(float *p) const { p[0] = v[0]; } };
+template <> struct XVec<2> { float v[2];
+    __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]); } };
+template <> struct XVec<4> { float v[4];
+    __device__ __forceinline__ void load(const float *p) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); } };
+template <> struct XVec<8> { float v[8];
+    __device__ __forceinline__ void load(const float *p) {
+        const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; }
+    __device__ __forceinline__ void store(float *p) const {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]); } };
 
 template <int C, int DMAX, int NT, bool BWD>
 __global__ void __launch_bounds__(NT, 4)          // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
@@ -704,7 +731,8 @@ k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, co
     extern __shared__ __align__(16) float smem[];
     const int gs = part_ptr[blockIdx.x], rows = part_ptr[blockIdx.x + 1] - gs;
     if (rows > NT) return;
-    const int nv = ((rows + 1) * CP + 3) & ~3;
+    const int R = sell_padR(rows);
+    const int nv = 2 * R * CP;                    // two copies, R is a multiple of 16
     float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
@@ -735,7 +763,7 @@ k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, co
     }
     const bool own = r >= 0;
 
-    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, rows, C, CP, F, T, tab);
+    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, rows, R, C, CP, F, T, tab);
     for (int t = 1; t <= T; ++t) {
         int q0, q1;
         step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
@@ -757,6 +785,7 @@ k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, co
                     if (d < DMAX) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) acc[c] = fmaf(v[d], xv[g].v[c], acc[c]);
+                        if (C % 4 == 3) asm volatile("" :: "v"(xv[g].v[CP - 1]));   // 12-B tail: keep it a ds_read_b128, not b96
                     }
                 }
             }
@@ -768,14 +797,81 @@ k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, co
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
             }
+            const int rB = R + sell_copyB(r, R);
+            XVec<CP> y;
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-                xb[r * CP + c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
+            for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
+            y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
         }
         __syncthreads();
         float *sw = xa; xa = xb; xb = sw;
     }
     chain_epilogue<BWD, NT>(xa, slab, OUT, gs, rows, C, CP, F);
+}
+
+// ------------------------------------------------------------------ pack-time slot planning
+// One wave per slice.  For every column k of the slice (one ds_read_b128 wave-instruction of the step loop) the 16
+// lanes of each hardware lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) take turns: a lane picks, among its
+// row's entries not yet placed, the (entry, copy) whose 16-byte bank slot is least loaded so far in this column.
+// Output per kept entry e: slot_of_e[e] = its column k, lc_of_e[e] = the LDS row index it reads (copy A: local column,
+// copy B: R + copyB(local column)); entries beyond dmax keep slot -1 (streamed tail).
+__global__ void __launch_bounds__(64)
+k_sell_plan(const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ part_ptr,
+            const int *__restrict__ slice_part, const int *__restrict__ perm, int dmax,
+            int *__restrict__ slot_of_e, int *__restrict__ lc_of_e)
+{
+    __shared__ int cols[64][33];
+    __shared__ volatile unsigned long long load[4];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int part = slice_part[s];
+    const int gs = part_ptr[part], rows = part_ptr[part + 1] - gs;
+    const int R = sell_padR(rows);
+    const int r = perm[(int64_t)s * 64 + lane];
+    int e0 = 0, cnt = 0;
+    if (r >= 0) { e0 = rowptr[gs + r]; cnt = rowptr[gs + r + 1] - e0; cnt = cnt < dmax ? cnt : dmax; }
+    for (int j = 0; j < cnt; ++j) cols[lane][j] = col[e0 + j] - gs;
+    unsigned rem = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+    const int w = wave_max_i(cnt);
+    const int l32 = lane & 31;
+    const bool g0 = l32 < 4 || (l32 >= 12 && l32 < 16) || (l32 >= 20 && l32 < 28);
+    const int g = (lane >> 5) * 2 + (g0 ? 0 : 1);
+    int turn = 0;                                  // rank of this lane inside its group, ascending lane order
+    for (int q = 0; q < l32; ++q) {
+        const bool q0 = q < 4 || (q >= 12 && q < 16) || (q >= 20 && q < 28);
+        turn += (q0 == g0);
+    }
+    const unsigned long long gmask32 = g0 ? 0x0FF0F00FULL : 0xF00F0FF0ULL;
+    const unsigned long long gmask = (lane >> 5) ? (gmask32 << 32) : gmask32;
+    const int zslot = rows & 15;
+    for (int k = 0; k < w; ++k) {
+        const bool padded = k >= cnt;
+        const unsigned long long pm = __ballot(padded);
+        if (turn == 0) load[g] = (pm & gmask) ? (1ULL << (4 * zslot)) : 0ULL;
+        for (int t = 0; t < 16; ++t) {
+            if (turn == t && !padded) {
+                unsigned long long L = load[g];
+                int best = 99, bj = 0, bpos = 0;
+                unsigned m = rem;
+                while (m) {
+                    const int j = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int a = cols[lane][j];
+                    const int b = R + sell_copyB(a, R);
+                    const int cA = (int)((L >> (4 * (a & 15))) & 15ULL), cB = (int)((L >> (4 * (b & 15))) & 15ULL);
+                    if (cA < best) { best = cA; bj = j; bpos = a; }
+                    if (cB < best) { best = cB; bj = j; bpos = b; }
+                    if (best == 0) break;
+                }
+                if (((L >> (4 * (bpos & 15))) & 15ULL) < 15ULL) L += 1ULL << (4 * (bpos & 15));
+                load[g] = L;
+                slot_of_e[e0 + bj] = k;
+                lc_of_e[e0 + bj] = bpos;
+                rem &= ~(1u << bj);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ orders 0/1/2 epilogue (ESCGNNModular._scatter)
@@ -977,7 +1073,6 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
     if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
     sd->val = sell->val; sd->lc = sell->lc; sd->perm = sell->perm; sd->slice_doff = sell->slice_doff;
     sd->slice_poff = sell->slice_poff; sd->part_slice_ptr = sell->part_slice_ptr; sd->dmax = sell->dmax;
-    if (sell->lanes_per_row != 1 && sell->lanes_per_row != 2) return fail(ESCAT_EINVAL, "escat_sell.lanes_per_row must be 1 or 2");
     return ESCAT_OK;
 }
 
@@ -985,29 +1080,15 @@ template <int DMAX, bool BWD>
 static int launch_bsr3_sell_d(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
                               const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
-    if (NT <= 256) LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 256, BWD, 1>), 256);
-    else           LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 512, BWD, 1>), 512);
-    return ESCAT_OK;
-}
-template <int DMAX, bool BWD>
-static int launch_bsr3_sell2_d(const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
-                               const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
-{
-    LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 1024, BWD, 2>), 1024);
+    if (NT <= 256) LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 256, BWD>), 256);
+    else           LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 512, BWD>), 512);
     return ESCAT_OK;
 }
 template <bool BWD>
-static int launch_bsr3_sell(int lpr, int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
+static int launch_bsr3_sell(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
                             size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F,
                             hipStream_t st)
 {
-    if (lpr == 2) {
-        switch (sd.dmax) {
-            case 8:  return launch_bsr3_sell2_d<8, BWD>(rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-            case 11: return launch_bsr3_sell2_d<11, BWD>(rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-        }
-        return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: two-lane BSR-3 packs must use 8 or 11", sd.dmax);
-    }
     switch (sd.dmax) {
         case 8:  return launch_bsr3_sell_d<8, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
         case 12: return launch_bsr3_sell_d<12, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
@@ -1073,12 +1154,11 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
         const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
         if (lds <= LDS_BUDGET) {
             const int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
-            const size_t nv = (((size_t)max_part_rows + 1) * CP + 3) & ~(size_t)3;
+            const size_t nv = (size_t)2 * sell_padR(max_part_rows) * CP;
             const size_t lds_s = (2 * nv + (size_t)max_part_rows * C * F) * sizeof(float);
             if (max_part_rows <= 512 && sell && force != 2 && lds_s <= LDS_BUDGET) {
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
-                if (sell->lanes_per_row != 1) return fail(ESCAT_EINVAL, "CSR packs use one lane per row");
                 rc = launch_csr_sell<BWD>(C, max_part_rows, rowptr, col, val, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
             } else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
@@ -1161,11 +1241,11 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
     const int force = chain_path_override();
     if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3) {
         const size_t lds = (size_t)max_part_rows * 3 * (2 + F) * sizeof(float);
-        const size_t lds_s = (2 * ((size_t)max_part_rows + 1) * 4 + (size_t)max_part_rows * 3 * F) * sizeof(float);
+        const size_t lds_s = ((size_t)2 * 2 * sell_padR(max_part_rows) * 4 + (size_t)max_part_rows * 3 * F) * sizeof(float);
         if (lds <= LDS_BUDGET && lds_s <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
-            rc = launch_bsr3_sell<BWD>(sell->lanes_per_row, max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
+            rc = launch_bsr3_sell<BWD>(max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_bsr3_sell");
             return ESCAT_OK;
@@ -1295,3 +1375,17 @@ extern "C" int escat_scatter_orders_bwd_f32(const float *W1, const float *dW, in
     CHECK_LAUNCH("k_scatter_orders_bwd");
     return ESCAT_OK;
 }
+
+extern "C" int escat_sell_plan_slots(const int32_t *rowptr, const int32_t *col, const int32_t *part_ptr,
+                                     const int32_t *slice_part, const int32_t *perm, int n_slices, int dmax,
+                                     int32_t *slot_of_e, int32_t *lc_of_e, void *stream)
+{
+    if (!rowptr || !col || !part_ptr || !slice_part || !perm || !slot_of_e || !lc_of_e) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (dmax < 1 || dmax > 32) return fail(ESCAT_ERANGE, "dmax=%d outside [1,32]", dmax);
+    if (n_slices <= 0) return n_slices == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative n_slices");
+    hipLaunchKernelGGL(k_sell_plan, dim3(n_slices), dim3(64), 0, S(stream), rowptr, col, part_ptr, slice_part, perm, dmax,
+                       slot_of_e, lc_of_e);
+    CHECK_LAUNCH("k_sell_plan");
+    return ESCAT_OK;
+}
+

@@ -80,24 +80,39 @@ def _cumsum0(t):
     return out
 
 
+def sell_pad_rows(rows: int) -> int:
+    """R of include/escat.h: rows of one LDS vector copy (part rows + the zero row, rounded up to 16)."""
+    return (rows + 1 + 15) & ~15
+
+
+def sell_copy_b(p, R: int):
+    """row of local column p inside copy B (see sell_copyB in csrc/escat.hip); p may be an int or an integer ndarray/tensor."""
+    m = 8 if R >= 256 else max(R.bit_length() - 1, 0)
+    if m < 5:
+        return p
+    blk, lim = 1 << m, (R >> m) << m
+    lo = p & (blk - 1)
+    q = (p & ~(blk - 1)) | (lo >> 4) | ((lo & 15) << (m - 4))
+    if isinstance(p, int):
+        return q if p < lim else p
+    return np.where(p < lim, q, p) if isinstance(p, np.ndarray) else torch.where(p < lim, q, p)
+
+
 class Sell:
     """
     SELL-64 pack of a CSR (val (nnz,)) or BSR-3 (val (nnz,3,3)) operator; layout in
-    include/escat.h (escat_sell).  Built with torch index ops on the operator's device.
-    lanes_per_row = 2 (BSR-3): lanes 2i, 2i+1 of a slice share row i; lane h holds entries h, h+2, ... of the row.
+    include/escat.h (escat_sell).  Built with torch index ops on the operator's device;
+    the slot order of every row's entries and the LDS vector copy each gather reads come
+    from libescat's escat_sell_plan_slots (bank-conflict-aware, one wave per slice).
     """
 
-    def __init__(self, form, lanes_per_row: int = 1):
+    def __init__(self, form):
+        from . import _lib
         dev = form.rowptr.device
         V = 9 if form.val.dim() == 3 else 1
-        L = lanes_per_row
-        assert L in (1, 2) and (L == 1 or V == 9)
-        caps = _SELL_DMAX[V] if L == 1 else (8, 11)
-        need = (form.max_row_nnz + L - 1) // L
-        self.dmax = next((c for c in caps if c >= need), caps[-1])
-        self.lanes_per_row = L
+        caps = _SELL_DMAX[V]
+        self.dmax = next((c for c in caps if c >= form.max_row_nnz), caps[-1])
         dmax = self.dmax
-        RPS = 64 // L                                   # rows per slice
         n, nnz = form.n, form.nnz
         rp = form.rowptr.long()
         deg = rp[1:] - rp[:-1]
@@ -105,32 +120,39 @@ class Sell:
         n_parts = form.n_parts
         part_rows = pp[1:] - pp[:-1]
         part_of_row = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_rows)
-        dcl = deg.clamp(max=dmax * L)
-        order = torch.argsort(part_of_row * (dmax * L + 1) + (dmax * L - dcl), stable=True)     # rows in slot order
-        part_slices = (part_rows + RPS - 1) // RPS
+        dcl = deg.clamp(max=dmax)
+        order = torch.argsort(part_of_row * (dmax + 1) + (dmax - dcl), stable=True)     # rows in lane order
+        part_slices = (part_rows + 63) // 64
         psp = _cumsum0(part_slices)
         n_slices = int(psp[-1])
-        # sorted position i (row order[i], part part_of_row[i]) -> first lane of its slot
-        slot0 = psp[part_of_row] * 64 + (torch.arange(n, device=dev) - pp[part_of_row]) * L
+        # sorted position i (row order[i], part part_of_row[i]) -> its lane
+        slot0 = psp[part_of_row] * 64 + (torch.arange(n, device=dev) - pp[part_of_row])
         perm = torch.full((n_slices * 64,), -1, dtype=torch.int32, device=dev)
-        lrow = (order - pp[part_of_row]).to(torch.int32)
+        perm[slot0] = (order - pp[part_of_row]).to(torch.int32)
         slot_cnt = torch.zeros(n_slices * 64, dtype=torch.int64, device=dev)
-        for h in range(L):
-            perm[slot0 + h] = lrow
-            slot_cnt[slot0 + h] = (dcl[order] - h + L - 1) // L          # entries h, h+L, ... below the cap
+        slot_cnt[slot0] = dcl[order]
         w = slot_cnt.view(n_slices, 64).max(dim=1).values
         doff, poff = _cumsum0(w), _cumsum0((w + 1) // 2)
         row_slot0 = torch.empty(n, dtype=torch.int64, device=dev)
         row_slot0[order] = slot0
+        slice_part = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_slices)
+        # slot (column of the slice) and LDS row of every kept entry
+        slot_of_e = torch.full((max(nnz, 1),), -1, dtype=torch.int32, device=dev)
+        lc_of_e = torch.zeros(max(nnz, 1), dtype=torch.int32, device=dev)
+        if not form.rowptr.is_cuda:
+            raise RuntimeError("escat: SELL packs are planned on the GPU (escat_sell_plan_slots); operator is on " + str(dev))
+        sp32 = slice_part.to(torch.int32)
+        with torch.cuda.device(dev):
+            rc = _lib.load().escat_sell_plan_slots(
+                form.rowptr.data_ptr(), form.col.data_ptr(), form.part_ptr.data_ptr(), sp32.data_ptr(), perm.data_ptr(),
+                n_slices, dmax, slot_of_e.data_ptr(), lc_of_e.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "escat_sell_plan_slots")
+        e_k = torch.nonzero(slot_of_e[:nnz] >= 0).flatten()
         row_of_e = torch.repeat_interleave(torch.arange(n, device=dev), deg)
-        d_of_e = torch.arange(nnz, device=dev) - rp[row_of_e]
-        keep = d_of_e < dmax * L
-        e_k = torch.nonzero(keep).flatten()
         r_k = row_of_e[e_k]
-        d_k = d_of_e[e_k] // L
-        sl = row_slot0[r_k] + d_of_e[e_k] % L
+        sl = row_slot0[r_k]
         s_k, lane = sl // 64, sl % 64
-        drow = doff[s_k] + d_k
+        drow = doff[s_k] + slot_of_e[e_k].long()
         total_d, total_p = int(doff[-1]), int(poff[-1])
         if V == 9:
             val = torch.zeros(max(total_d, 1) * 576, dtype=torch.float32, device=dev)
@@ -141,12 +163,11 @@ class Sell:
         else:
             val = torch.zeros(max(total_d, 1) * 64, dtype=torch.float32, device=dev)
             val[drow * 64 + lane] = form.val[e_k]
-        # local columns, one int per (slice, slot, lane); slots past a row's end point at the part's all-zero LDS row
-        slice_part = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_slices)
+        # LDS rows, one int per (slice, slot, lane); slots past a row's end point at the part's all-zero LDS row
         zc = part_rows[slice_part]                                                        # per slice
         slice_of_drow = torch.repeat_interleave(torch.arange(n_slices, device=dev), w)
         lcu = zc[slice_of_drow].repeat_interleave(64)                                     # (total_d*64,)
-        lcu[drow * 64 + lane] = form.col.long()[e_k] - pp[part_of_row[r_k]]
+        lcu[drow * 64 + lane] = lc_of_e[e_k].long()
         npair = (w + 1) // 2
         slice_of_pair = torch.repeat_interleave(torch.arange(n_slices, device=dev), npair)
         j2 = torch.arange(total_p, device=dev) - poff[slice_of_pair]
@@ -168,6 +189,7 @@ class Sell:
         self.part_slice_ptr = psp.to(torch.int32)
         self.n_slices = n_slices
         self.pad_ratio = float(total_d * 64) / max(float(dcl.sum()), 1.0)
+        self.slot_of_e, self.lc_of_e = slot_of_e, lc_of_e      # kept for tests / diagnostics (8 B per entry)
 
 
 class SellGlobal:
@@ -233,14 +255,7 @@ class _Csr:
     def sell(self):
         """packed SELL-64 copy for the register-resident kernels (None if the parts are too large)."""
         if self._sell is None and 0 < self.max_part_rows <= SELL_MAX_PART_ROWS and self.nnz > 0:
-            # opt-in experiment (ESCAT_SELL_LPR=2): two lanes per row for BSR-3 parts of more than 256 rows, so that a
-            # 1024-thread workgroup needs <= 128 VGPRs and two workgroups share a CU (one loading, one stepping).
-            # Measured on cfg2 it LOSES (Q chain 1.19 ms vs 0.73 ms): the per-lane capacity of 11 blocks spills 21
-            # VGPRs that are reloaded every step, and with half the slots per lane the LDS gathers are no longer
-            # batched.  Kept for the record and for tests; default is one lane per row.
-            two = self.val.dim() == 3 and self.max_part_rows > 256 and self.max_row_nnz <= 22 \
-                and os.environ.get("ESCAT_SELL_LPR", "1") == "2"
-            self._sell = Sell(self, 2 if two else 1)
+            self._sell = Sell(self)
         return self._sell
 
 

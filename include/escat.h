@@ -66,8 +66,10 @@ typedef struct { int32_t step, slot, sign, chan; } escat_event;
  *   CSR   val[(doff_s + d)*64 + lane]
  *   BSR-3 val[(doff_s + d)*576 + {lane*4+0..3 | 256+lane*4+0..3 | 512+lane}]
  *         = block floats 0-3 | 4-7 | 8
- *   lc[(poff_s + d/2)*64 + lane] = local col of slot d | local col of slot d+1 << 16
- *         (local = column - first row of the part; 0 where the row is shorter)
+ *   lc[(poff_s + d/2)*64 + lane] = LDS row of slot d | LDS row of slot d+1 << 16, where the LDS row of an entry
+ *         with local column a (= column - first row of the part) is a (copy A of the vector) or R + copyB(a)
+ *         (copy B; R = rows of the part + 1 rounded up to 16, copyB rotates bits 0-3 of a to the top of its
+ *         256-row block), as chosen by escat_sell_plan_slots; slots past a row's end hold `rows` (the zero row)
  * with doff_s = slice_doff[s], poff_s = slice_poff[s] (prefix sums of w_s and
  * ceil(w_s/2)), perm[s*64 + lane] = local row served by that lane (-1: none),
  * part_slice_ptr[p] = first slice of part p.  Entries beyond dmax stay in the
@@ -82,13 +84,20 @@ typedef struct {
     const int32_t  *part_slice_ptr;
     int32_t         dmax;
     int32_t         n_slices;
-    int32_t         lanes_per_row;  /* 1, or 2 (BSR-3 only): lanes 2i, 2i+1 of a slice share row i (32 rows per slice), lane h
-                                       holds entries h, h+2, ... of the row (dmax = per-lane capacity: 8 or 11) */
+    int32_t         reserved;       /* 0 */
     const int32_t  *col32;          /* NULL, or: one GLOBAL (block) column per slot, [(doff_s + d)*64 + lane], -1 = padding.
                                        Then the pack covers the whole operator (slices of 64 rows sorted by length inside
                                        windows, perm = global row, lc / slice_poff / part_slice_ptr unused, no dmax cap)
                                        and drives the multi-launch path for graphs that do not fit LDS (BSR-3 only). */
 } escat_sell;
+
+/* Pack-time planning for escat_sell: for every entry e among the first dmax of its row, the slot (column of its
+ * slice) and the LDS row (vector copy A or B) it will use, chosen so that the 16 lanes of each ds_read_b128 lane
+ * group land on distinct 16-byte bank slots where possible.  slice_part[s] = part of slice s; slot_of_e must be
+ * pre-filled with -1 (entries beyond dmax keep it). */
+int escat_sell_plan_slots(const int32_t *rowptr, const int32_t *col, const int32_t *part_ptr,
+                          const int32_t *slice_part, const int32_t *perm, int n_slices, int dmax,
+                          int32_t *slot_of_e, int32_t *lc_of_e, void *stream);
 
 /* last error message of the calling thread ("" if none). */
 const char *escat_last_error(void);
