@@ -25,10 +25,10 @@ class EscatEvent(ctypes.Structure):
 
 
 class EscatSell(ctypes.Structure):
-    _fields_ = [("val", ctypes.c_void_p), ("lc", ctypes.c_void_p), ("perm", ctypes.c_void_p),
-                ("slice_doff", ctypes.c_void_p), ("slice_poff", ctypes.c_void_p), ("part_slice_ptr", ctypes.c_void_p),
-                ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("col32", ctypes.c_void_p)]
+    _fields_ = [("val", ctypes.c_void_p), ("lc", ctypes.c_void_p), ("lane_meta", ctypes.c_void_p),
+                ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("slices_per_part", ctypes.c_int32),
+                ("reserved", ctypes.c_int32),
+                ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/escat.h declares

@@ -499,21 +499,235 @@ __host__ __device__ __forceinline__ int sell_copyB(int p, int R)
     return (p & ~(blk - 1)) | (lo >> 4) | ((lo & 15) << (m - 4));
 }
 
-// loads x (fwd) or the upstream-gradient slab (bwd) of a part into LDS, applies the
-// step-0 events (fwd) / forms the Horner start (bwd); returns the event cursor.
+// events of step `st`: [q0, q1) in the table; moves the cursor (fwd: up, bwd: down)
+template <bool BWD>
+__device__ __forceinline__ void step_range(const EvTable &tab, int st, int &p, int &q0, int &q1)
+{
+    if (!BWD) { q0 = p; q1 = p; while (q1 < tab.n && tab.e[q1].step == st) ++q1; p = q1; }
+    else { q1 = p; q0 = p; while (q0 > 0 && tab.e[q0 - 1].step == st) --q0; p = q0; }
+}
+
+template <bool BWD>
+__device__ __forceinline__ float apply_events(const EvTable &tab, int q0, int q1, int c, float y, float *o)
+{
+    if (BWD) {
+        for (int k = q0; k < q1; ++k)
+            if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -o[tab.e[k].slot] : o[tab.e[k].slot];
+    } else {
+        for (int k = q0; k < q1; ++k)
+            if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(o, y, tab.e[k].slot, tab.e[k].sign);
+    }
+    return y;
+}
+
+// Packed operator for these kernels ("SELL-64": sliced ELLPACK, slice = one wave).
+// Every part owns `nsl` slices (nsl = max part rows / 64, rounded up; trailing ones may be empty).  Inside a part the
+// rows are sorted by length (descending) and cut into slices of 64; slice s stores its first w_s = min(longest row,
+// dmax) entries slot-major,
+//   CSR   val[(doff_s + d) * 64 + lane]
+//   BSR-3 val[(doff_s + d) * 576 + {0: lane*4 + 0..3 | 256: lane*4 + 0..3 | 512: lane}]
+//         (the 9 floats of a block as two float4 pieces and one scalar piece)
+//   lc[(poff_s + d/2) * 64 + lane] = LDS row of slot d | LDS row of slot d+1 << 16, for d < w_s rounded up to 4
+// so that every load of a wave is one fully coalesced 256-B or 1-KiB access, and the sort makes w_s the length of
+// (nearly) every row of the slice: few idle slots.  Slots past a row's end hold value 0 and LDS row = rows of the part
+// (the all-zero row), so the step loop needs no per-lane predication.
+//   lane_meta[(s*64 + lane)*3 + {0,1,2}] = { row | tail_n << 10,  tail_e0,  slice word }:
+//       row = the row (local to the part) the lane serves, 0x3ff = none; tail_e0 / tail_n = the row's entries beyond
+//       dmax in the canonical arrays (streamed from L2 every step); slice words of lanes 0..4 = doff_s, poff_s, w_s,
+//       first row of the part, rows of the part -- ONE 12-byte load per lane brings everything a wave needs to start
+//       a part, with no dependent second hop.
+struct SellDev {
+    const float *val; const unsigned *lc; const int *lane_meta;
+    int dmax, nsl;
+};
+
+#define SLOT_GROUP 4      // slots issued together: their LDS gathers are in flight at once
+
+// debug build only (-DESCAT_STAMPS, see tools/stamps.py): wall-clock stamps of the phases of every part
+#ifdef ESCAT_STAMPS
+__device__ unsigned long long *g_stamps = nullptr;
+#define STAMP(part, i) do { if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)(part) * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int escat_debug_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#else
+#define STAMP(part, i)
+#endif
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int CP> struct XVec;
+template <> struct XVec<1> { float v[1];
+    __device__ __forceinline__ void load(const float *p) { v[0] = p[0]; }
+    __device__ __forceinline__ void store(float *p) const { p[0] = v[0]; } };
+template <> struct XVec<2> { float v[2];
+    __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]); } };
+template <> struct XVec<4> { float v[4];
+    __device__ __forceinline__ void load(const float *p) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); } };
+template <> struct XVec<8> { float v[8];
+    __device__ __forceinline__ void load(const float *p) {
+        const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; }
+    __device__ __forceinline__ void store(float *p) const {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]); } };
+
+// ---- the operator of one row, in registers.  Two flavours with one interface:
+//   load(sd, doff, poff, w, lane)  issue the (coalesced) loads of this lane's slots
+//   gather(xa, w, acc)          acc += sum over slots of value * x[LDS row]   (one step)
+//   tail(...)                   entries beyond dmax, streamed
+template <int DMAX> struct OpBsr3 {
+    static constexpr int C = 3, CP = 4, MINW = 1;
+    // a block's 9 floats as the three pieces they are loaded in
+    float4 b0[DMAX], b1[DMAX];
+    float b2[DMAX];
+    unsigned lc[(DMAX + 1) / 2];
+    // Every slot register is written by exactly one UNCONDITIONAL load per part: a slot past the slice's width re-reads
+    // the last real slot (same address for the whole wave: served by the cache) and is never consumed, gather() stops at
+    // the width.  Written with a branch per slot ("load if d < w, else keep / zero") the compiler merges loaded and
+    // kept values through register copies that need the data -- a vmcnt(0) after every slot, i.e. twenty serial HBM
+    // round trips per part instead of one burst (measured with tools/stamps.py: 16 us vs the ~9 us the bytes take).
+    __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)
+    {
+        const float *vb = sd.val + (int64_t)doff * 576;
+        const int wl = w > 0 ? w - 1 : 0;         // (an empty slice reads the pack's padding slot)
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            const int dd = d < wl ? d : wl;       // wave-uniform
+            b0[d] = *reinterpret_cast<const float4 *>(vb + dd * 576 + lane * 4);
+            b1[d] = *reinterpret_cast<const float4 *>(vb + dd * 576 + 256 + lane * 4);
+            b2[d] = vb[dd * 576 + 512 + lane];
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < (DMAX + 1) / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
+    }
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&a)[3]) const
+    {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
+            if (d0 < w) {                         // wave-uniform: slice width, in groups
+                float4 xv[SLOT_GROUP];
+#pragma unroll
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) {               // lc holds LDS rows; a row is 4 floats
+                        const unsigned row = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
+                        xv[g] = *reinterpret_cast<const float4 *>(xa + row * 4u);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) {
+                        const float x0 = xv[g].x, x1 = xv[g].y, x2 = xv[g].z;
+                        a[0] = fmaf(b0[d].x, x0, a[0]); a[0] = fmaf(b0[d].y, x1, a[0]); a[0] = fmaf(b0[d].z, x2, a[0]);
+                        a[1] = fmaf(b0[d].w, x0, a[1]); a[1] = fmaf(b1[d].x, x1, a[1]); a[1] = fmaf(b1[d].y, x2, a[1]);
+                        a[2] = fmaf(b1[d].z, x0, a[2]); a[2] = fmaf(b1[d].w, x1, a[2]); a[2] = fmaf(b2[d], x2, a[2]);
+                        // keep the pad lane live: otherwise the gather is narrowed to ds_read_b96 (8 LDS cycles, 8-lane
+                        // groups on 32 banks) instead of ds_read_b128 (4 cycles, the 16-lane groups the pack is planned for)
+                        asm volatile("" :: "v"(xv[g].w));
+                    }
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ void tail(const float *__restrict__ blk, const int *__restrict__ col, int e0, int n,
+                                                int gs, const float *xa, float (&a)[3])
+    {
+        for (int e = e0; e < e0 + n; ++e) {       // rows longer than the pack: from L2, every step
+            const float *bb = blk + (int64_t)e * 9;
+            const float *x = xa + (col[e] - gs) * 4;
+            const float x0 = x[0], x1 = x[1], x2 = x[2];
+            a[0] = fmaf(bb[0], x0, a[0]); a[0] = fmaf(bb[1], x1, a[0]); a[0] = fmaf(bb[2], x2, a[0]);
+            a[1] = fmaf(bb[3], x0, a[1]); a[1] = fmaf(bb[4], x1, a[1]); a[1] = fmaf(bb[5], x2, a[1]);
+            a[2] = fmaf(bb[6], x0, a[2]); a[2] = fmaf(bb[7], x1, a[2]); a[2] = fmaf(bb[8], x2, a[2]);
+        }
+    }
+};
+
+template <int CC, int DMAX> struct OpCsr {
+    static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
+    static constexpr int C = CC, CP = CC == 1 ? 1 : (CC == 2 ? 2 : (CC <= 4 ? 4 : 8));
+    static constexpr int MINW = 4;                // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
+    float v[DMAX];
+    unsigned lc[DMAX / 2];
+    __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)   // see OpBsr3::load
+    {
+        const int wl = w > 0 ? w - 1 : 0;
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = sd.val[(int64_t)(doff + (d < wl ? d : wl)) * 64 + lane];
+#pragma unroll
+        for (int j2 = 0; j2 < DMAX / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];     // LDS rows, two per register
+    }
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[CC]) const
+    {
+#pragma unroll
+        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
+            if (d0 < w) {
+                XVec<CP> xv[SLOT_GROUP];
+#pragma unroll
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) xv[g].load(xa + ((d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu)) * (unsigned)CP);
+                }
+#pragma unroll
+                for (int g = 0; g < SLOT_GROUP; ++g) {
+                    const int d = d0 + g;
+                    if (d < DMAX) {
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) acc[c] = fmaf(v[d], xv[g].v[c], acc[c]);
+                        if (CC % 4 == 3) asm volatile("" :: "v"(xv[g].v[CP - 1]));   // 12-B tail: keep it a ds_read_b128, not b96
+                    }
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
+                                                int gs, const float *xa, float (&acc)[CC])
+    {
+        for (int e = e0; e < e0 + n; ++e) {
+            const float vv = val[e];
+            const float *x = xa + (col[e] - gs) * CP;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
+        }
+    }
+};
+
+
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// n floats global -> LDS without passing through registers (LDS-DMA, one dword per lane, 256 B per wave-instruction);
+// completion is counted in vmcnt like any load.
+template <int NT>
+__device__ __forceinline__ void dma_in(float *dst, const float *__restrict__ src, int n)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i0 = wave * 64; i0 < n; i0 += NT) {
+        const int i = i0 + lane;
+        if (i < n) __builtin_amdgcn_global_load_lds((glb_void_t *)(src + i), (lds_void_t *)(dst + i0), 4, 0, 0);
+    }
+}
+
+// builds the first vector of a part from its staged input (fwd: x in `inb`; bwd: the upstream-gradient slab), applies
+// the step-0 events (fwd) / forms the Horner start (bwd); returns the event cursor.  Ends with a barrier.
 template <bool BWD, int NT>
-__device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab, const float *__restrict__ IN,
-                                              int64_t first_row, int rows, int R, int C, int CP, int F, int T, const EvTable &tab)
+__device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab, const float *inb, int rows, int R, int C, int CP,
+                                              int F, int T, const EvTable &tab)
 {
     const int tid = threadIdx.x;
     const int nc = rows * C;
     int p;
     if (tid < CP) { xa[rows * CP + tid] = 0.f; xb[rows * CP + tid] = 0.f; }
     if (!BWD) {
-        const float *xg = IN + first_row * C;
         int p1 = 0; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
         for (int i = tid; i < nc; i += NT) {
-            const int c = i % C, r = i / C; const float y = xg[i];
+            const int c = i % C, r = i / C; const float y = inb[i];
             xa[r * CP + c] = y;
             xa[(R + sell_copyB(r, R)) * CP + c] = y;
             for (int k = 0; k < p1; ++k)
@@ -521,9 +735,6 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab,
         }
         p = p1;
     } else {
-        const float *gg = IN + first_row * C * F;
-        for (int i = tid; i < nc * F; i += NT) slab[i] = gg[i];
-        __syncthreads();
         int p0 = tab.n; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
         for (int i = tid; i < nc; i += NT) {
             const int c = i % C, r = i / C; float y = 0.f;
@@ -553,262 +764,114 @@ __device__ __forceinline__ void chain_epilogue(const float *xa, const float *sla
     }
 }
 
-// events of step `st`: [q0, q1) in the table; moves the cursor (fwd: up, bwd: down)
-template <bool BWD>
-__device__ __forceinline__ void step_range(const EvTable &tab, int st, int &p, int &q0, int &q1)
+// ---- the register-resident chain kernel: persistent workgroups, software-pipelined over parts.
+// A workgroup walks parts blockIdx.x, + gridDim.x, ...  While part g steps, the metadata of part g' = g + gridDim.x
+// is fetched (one 12-B load per lane) and its input is copied into LDS by DMA; the moment g's last step is done --
+// its operator registers are dead -- the operator loads of g' are issued, and g's epilogue (slab -> HBM) and g''s
+// prologue (input -> first vector) run underneath them.  What stays exposed per part is the operator stream itself
+// (a CU pulls ~12-24 GB/s from HBM); the metadata hops, the input latency and the output stores are hidden.
+//   LDS: xa | xb (two copies each) | slab | inb   -- inb = staged x (fwd) or the second slab (bwd, `early`);
+//   bwd without room for two slabs (`early` = 0) copies the next input in after the last step instead.
+template <class Op, int NT, bool BWD>
+__global__ void __launch_bounds__(NT, Op::MINW)
+k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev sd, const float *__restrict__ IN,
+             float *__restrict__ RES, int T, EvTable tab, int F, int n_parts, int max_rows, int early)
 {
-    if (!BWD) { q0 = p; q1 = p; while (q1 < tab.n && tab.e[q1].step == st) ++q1; p = q1; }
-    else { q1 = p; q0 = p; while (q0 > 0 && tab.e[q0 - 1].step == st) --q0; p = q0; }
-}
-
-template <bool BWD>
-__device__ __forceinline__ float apply_events(const EvTable &tab, int q0, int q1, int c, float y, float *o)
-{
-    if (BWD) {
-        for (int k = q0; k < q1; ++k)
-            if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -o[tab.e[k].slot] : o[tab.e[k].slot];
-    } else {
-        for (int k = q0; k < q1; ++k)
-            if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(o, y, tab.e[k].slot, tab.e[k].sign);
-    }
-    return y;
-}
-
-// Packed operator for these kernels ("SELL-64": sliced ELLPACK, slice = one wave).
-// Inside each part the rows are sorted by length (descending) and cut into slices
-// of 64; slice s stores its first w_s = min(longest row, dmax) entries slot-major,
-//   CSR   val[(doff_s + d) * 64 + lane]
-//   BSR-3 val[(doff_s + d) * 576 + {0: lane*4 + 0..3 | 256: lane*4 + 0..3 | 512: lane}]
-//         (the 9 floats of a block as two float4 pieces and one scalar piece)
-//   lc[(poff_s + d/2) * 64 + lane] = local column of slot d | local column of slot d+1 << 16
-// so that every load of a wave is one fully coalesced 256-B or 1-KiB access, and
-// the sort makes w_s the length of (nearly) every row of the slice: few idle slots.
-// Slots past a row's end hold value 0 and local column = rows of the part (the
-// all-zero LDS row), so the step loop needs no per-lane predication.
-// perm[s*64 + lane] is the row (local to the part) that lane serves, -1 = none.
-struct SellDev {
-    const float *val; const unsigned *lc; const int *perm;
-    const int *slice_doff; const int *slice_poff; const int *part_slice_ptr;
-    int dmax;
-};
-
-#define SLOT_GROUP 4      // slots issued together: their LDS gathers are in flight at once
-
-template <int DMAX, int NT, bool BWD>
-__global__ void __launch_bounds__(NT)
-k_chain_bsr3_sell(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
-                  const int *__restrict__ part_ptr, SellDev sd, const float *__restrict__ X, float *__restrict__ OUT,
-                  int T, EvTable tab, int F)
-{
-    constexpr int GRP = SLOT_GROUP;
+    constexpr int C = Op::C, CP = Op::CP;
     extern __shared__ __align__(16) float smem[];
-    const int gs = part_ptr[blockIdx.x], brows = part_ptr[blockIdx.x + 1] - gs;
-    if (brows > NT) return;                       // host guarantees max_part_rows <= NT
-    const int R = sell_padR(brows);
-    const int nv = 2 * R * 4;                     // two copies of a float4-per-node vector (incl. the zero node)
+    const int nv = 2 * sell_padR(max_rows) * CP;                 // two copies per vector, a multiple of 32 floats
+    const int slab_sz = (max_rows * C * F + 3) & ~3;
     float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
-    const unsigned zoff = (unsigned)brows * 4u;
+    float *inb = (BWD && !early) ? slab : slab + slab_sz;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int in_w = BWD ? C * F : C;                            // input floats per row
 
-    float b[DMAX * 9];
-    unsigned lc[(DMAX + 1) / 2];
-    int r = -1, e0 = 0, deg = 0, w = 0;
-#pragma unroll
-    for (int q = 0; q < DMAX * 9; ++q) b[q] = 0.f;
-#pragma unroll
-    for (int q = 0; q < (DMAX + 1) / 2; ++q) lc[q] = zoff | (zoff << 16);
-    if (wave < ns) {
-        const int s = __builtin_amdgcn_readfirstlane(s0 + wave);
-        const int doff = __builtin_amdgcn_readfirstlane(sd.slice_doff[s]), poff = __builtin_amdgcn_readfirstlane(sd.slice_poff[s]);
-        w = __builtin_amdgcn_readfirstlane(sd.slice_doff[s + 1] - doff);
-        r = sd.perm[s * 64 + lane];
-        if (r >= 0) { e0 = rowptr[gs + r]; deg = rowptr[gs + r + 1] - e0; }
-        const float *vb = sd.val + (int64_t)doff * 576;
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d) {
-            if (d < w) {                          // wave-uniform
-                const float4 p0 = *reinterpret_cast<const float4 *>(vb + d * 576 + lane * 4);
-                const float4 p1 = *reinterpret_cast<const float4 *>(vb + d * 576 + 256 + lane * 4);
-                const float p2 = vb[d * 576 + 512 + lane];
-                b[9 * d + 0] = p0.x; b[9 * d + 1] = p0.y; b[9 * d + 2] = p0.z; b[9 * d + 3] = p0.w;
-                b[9 * d + 4] = p1.x; b[9 * d + 5] = p1.y; b[9 * d + 6] = p1.z; b[9 * d + 7] = p1.w;
-                b[9 * d + 8] = p2;
-            }
-        }
-#pragma unroll
-        for (int j2 = 0; j2 < (DMAX + 1) / 2; ++j2) {
-            if (2 * j2 < w) {
-                const unsigned v = sd.lc[(int64_t)(poff + j2) * 64 + lane];
-                lc[j2] = ((v & 0xffffu) * 4u) | (((v >> 16) * 4u) << 16);      // float offsets into the LDS vector
-            }
-        }
+    int part = blockIdx.x;
+    if (part >= n_parts) return;
+    Op op;
+    // first part: nothing to hide behind
+    int rt, te0, sw;
+    {
+        const int *lm = sd.lane_meta + ((int64_t)(part * sd.nsl + wave) * 64 + lane) * 3;
+        rt = lm[0]; te0 = lm[1]; sw = lm[2];
+        const int gs0 = __builtin_amdgcn_readlane(sw, 3), rows0 = __builtin_amdgcn_readlane(sw, 4);
+        dma_in<NT>(BWD ? slab : inb, IN + (int64_t)gs0 * in_w, rows0 * in_w);
     }
-    const bool own = r >= 0;
-    const int rB = own ? R + sell_copyB(r, R) : 0;
+    int prev_gs = 0, prev_rows = -1;              // part whose result is still in LDS (epilogue pending)
+    for (;;) {
+        const int doff = __builtin_amdgcn_readlane(sw, 0), poff = __builtin_amdgcn_readlane(sw, 1);
+        const int w = __builtin_amdgcn_readlane(sw, 2);
+        const int gs = __builtin_amdgcn_readlane(sw, 3), rows = __builtin_amdgcn_readlane(sw, 4);
+        // the operator registers are dead here: refill them ...
+        STAMP(part, 0);
+        op.load(sd, doff, poff, w, lane);
+        STAMP(part, 1);
+        // ... and store the previous part's result underneath the stream
+        if (prev_rows >= 0) chain_epilogue<BWD, NT>(xa, slab, RES, prev_gs, prev_rows, C, CP, F);
+        STAMP(part, 2);
 
-    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, brows, R, 3, 4, F, T, tab);
-    for (int t = 1; t <= T; ++t) {
-        int q0, q1;
-        step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const int R = sell_padR(rows);
+        const int r = (rt & 0x3ff) == 0x3ff ? -1 : (rt & 0x3ff);
+        const int tn = (int)((unsigned)rt >> 10);
+        const bool own = r >= 0;
+        const int rB = own ? R + sell_copyB(r, R) : 0;
+        // input staged?  (first part, or the late copy of the single-slab backward: wait for it -- and, loads being
+        // returned in order, for the operator issued after it; otherwise it landed many steps ago)
+        if (prev_rows < 0 || (BWD && !early)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                          // every wave's copy has landed; the epilogue's LDS reads are done
+        STAMP(part, 3);
+        int p = chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab);
+        STAMP(part, 4);
+
+        const int next = part + gridDim.x;
+        const bool has_next = next < n_parts;     // uniform
+        int rtN = 0, te0N = 0, swN = 0;
+        if (has_next) {                           // metadata of the next part: lands during the first step
+            const int *lm = sd.lane_meta + ((int64_t)(next * sd.nsl + wave) * 64 + lane) * 3;
+            rtN = lm[0]; te0N = lm[1]; swN = lm[2];
+        }
+        bool staged = !(has_next && (!BWD || early));   // "nothing to stage early"
+        for (int t = 1; t <= T; ++t) {
+            int q0, q1;
+            step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
+            float acc[C];
 #pragma unroll
-        for (int d0 = 0; d0 < DMAX; d0 += GRP) {
-            if (d0 < w) {                         // wave-uniform: slice width, in groups
-                float4 xv[GRP];
+            for (int c = 0; c < C; ++c) acc[c] = 0.f;
+            op.gather(xa, w, acc);
+            if (own) {
+                if (tn) Op::tail(val, col, te0, tn, gs, xa, acc);
+                XVec<CP> y;
 #pragma unroll
-                for (int g = 0; g < GRP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) {
-                        const unsigned off = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
-                        xv[g] = *reinterpret_cast<const float4 *>(xa + off);
-                    }
-                }
+                for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
 #pragma unroll
-                for (int g = 0; g < GRP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) {
-                        const float x0 = xv[g].x, x1 = xv[g].y, x2 = xv[g].z;
-                        a0 = fmaf(b[9 * d + 0], x0, a0); a0 = fmaf(b[9 * d + 1], x1, a0); a0 = fmaf(b[9 * d + 2], x2, a0);
-                        a1 = fmaf(b[9 * d + 3], x0, a1); a1 = fmaf(b[9 * d + 4], x1, a1); a1 = fmaf(b[9 * d + 5], x2, a1);
-                        a2 = fmaf(b[9 * d + 6], x0, a2); a2 = fmaf(b[9 * d + 7], x1, a2); a2 = fmaf(b[9 * d + 8], x2, a2);
-                        // keep the pad lane live: otherwise the gather is narrowed to ds_read_b96 (8 LDS cycles, 8-lane
-                        // groups on 32 banks) instead of ds_read_b128 (4 cycles, the 16-lane groups the pack is planned for)
-                        asm volatile("" :: "v"(xv[g].w));
-                    }
-                }
+                for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
+                y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
+            }
+            __syncthreads();
+            float *tmp = xa; xa = xb; xb = tmp;
+#ifdef ESCAT_STAMPS
+            if (t == 1) STAMP(part, 5);
+#endif
+            if (!staged) {                        // after the first step: start the DMA of the next part's input
+                const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
+                dma_in<NT>(inb, IN + (int64_t)gsN * in_w, rowsN * in_w);
+                staged = true;
             }
         }
-        if (own) {
-            for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {   // rows longer than the pack: tail from L2
-                const float *bb = blk + (int64_t)e * 9;
-                const float *x = xa + (col[e] - gs) * 4;
-                const float x0 = x[0], x1 = x[1], x2 = x[2];
-                a0 = fmaf(bb[0], x0, a0); a0 = fmaf(bb[1], x1, a0); a0 = fmaf(bb[2], x2, a0);
-                a1 = fmaf(bb[3], x0, a1); a1 = fmaf(bb[4], x1, a1); a1 = fmaf(bb[5], x2, a1);
-                a2 = fmaf(bb[6], x0, a2); a2 = fmaf(bb[7], x1, a2); a2 = fmaf(bb[8], x2, a2);
-            }
-            float *o = slab + 3 * r * F;
-            a0 = apply_events<BWD>(tab, q0, q1, 0, a0, o);
-            a1 = apply_events<BWD>(tab, q0, q1, 0, a1, o + F);
-            a2 = apply_events<BWD>(tab, q0, q1, 0, a2, o + 2 * F);
-            const float4 y = make_float4(a0, a1, a2, 0.f);          // one 16-B store per copy: 32 banks serve 8 lanes
-            *reinterpret_cast<float4 *>(xb + 4 * r) = y;
-            *reinterpret_cast<float4 *>(xb + 4 * rB) = y;
+        prev_gs = gs; prev_rows = rows;
+        STAMP(part, 6);
+        if (!has_next) break;
+        {
+            const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
+            // fwd / early bwd with T == 0 never reached the in-loop DMA; the single-slab bwd copies now (its slab is dead)
+            if (!staged || (BWD && !early)) dma_in<NT>(inb, IN + (int64_t)gsN * in_w, rowsN * in_w);
+            if (!BWD || early) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged long ago: costs nothing
         }
-        __syncthreads();
-        float *sw = xa; xa = xb; xb = sw;
+        STAMP(part, 7);
+        part = next; rt = rtN; te0 = te0N; sw = swN;
+        if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
     }
-    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, brows, 3, 4, F);
-}
-
-template <int CP> struct XVec;
-template <> struct XVec<1> { float v[1];
-    __device__ __forceinline__ void load(const float *p) { v[0] = p[0]; }
-    __device__ __forceinline__ void store(float *p) const { p[0] = v[0]; } };
-template <> struct XVec<2> { float v[2];
-    __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
-    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]); } };
-template <> struct XVec<4> { float v[4];
-    __device__ __forceinline__ void load(const float *p) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); } };
-template <> struct XVec<8> { float v[8];
-    __device__ __forceinline__ void load(const float *p) {
-        const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 4);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; }
-    __device__ __forceinline__ void store(float *p) const {
-        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]); } };
-
-template <int C, int DMAX, int NT, bool BWD>
-__global__ void __launch_bounds__(NT, 4)          // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
-k_chain_csr_sell(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
-                 const int *__restrict__ part_ptr, SellDev sd, const float *__restrict__ X, float *__restrict__ OUT,
-                 int T, EvTable tab, int F)
-{
-    static_assert(DMAX % 2 == 0, "DMAX must be even (packed column offsets)");
-    constexpr int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
-    extern __shared__ __align__(16) float smem[];
-    const int gs = part_ptr[blockIdx.x], rows = part_ptr[blockIdx.x + 1] - gs;
-    if (rows > NT) return;
-    const int R = sell_padR(rows);
-    const int nv = 2 * R * CP;                    // two copies, R is a multiple of 16
-    float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s0 = sd.part_slice_ptr[blockIdx.x], ns = sd.part_slice_ptr[blockIdx.x + 1] - s0;
-    const unsigned zoff = (unsigned)rows * (unsigned)CP;
-
-    float v[DMAX];
-    unsigned lc[DMAX / 2];
-    int r = -1, e0 = 0, deg = 0, w = 0;
-#pragma unroll
-    for (int d = 0; d < DMAX; ++d) v[d] = 0.f;
-#pragma unroll
-    for (int q = 0; q < DMAX / 2; ++q) lc[q] = zoff | (zoff << 16);
-    if (wave < ns) {
-        const int s = s0 + wave;
-        const int doff = sd.slice_doff[s], poff = sd.slice_poff[s];
-        w = __builtin_amdgcn_readfirstlane(sd.slice_doff[s + 1] - doff);
-        r = sd.perm[s * 64 + lane];
-        if (r >= 0) { e0 = rowptr[gs + r]; deg = rowptr[gs + r + 1] - e0; }
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d)
-            if (d < w) v[d] = sd.val[(int64_t)(doff + d) * 64 + lane];
-#pragma unroll
-        for (int j2 = 0; j2 < DMAX / 2; ++j2)
-            if (2 * j2 < w) {
-                const unsigned u = sd.lc[(int64_t)(poff + j2) * 64 + lane];
-                lc[j2] = ((u & 0xffffu) * (unsigned)CP) | (((u >> 16) * (unsigned)CP) << 16);
-            }
-    }
-    const bool own = r >= 0;
-
-    int p = chain_prologue<BWD, NT>(xa, xb, slab, X, gs, rows, R, C, CP, F, T, tab);
-    for (int t = 1; t <= T; ++t) {
-        int q0, q1;
-        step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
-        float acc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
-            if (d0 < w) {
-                XVec<CP> xv[SLOT_GROUP];
-#pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) xv[g].load(xa + ((d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu)));
-                }
-#pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) acc[c] = fmaf(v[d], xv[g].v[c], acc[c]);
-                        if (C % 4 == 3) asm volatile("" :: "v"(xv[g].v[CP - 1]));   // 12-B tail: keep it a ds_read_b128, not b96
-                    }
-                }
-            }
-        }
-        if (own) {
-            for (int e = e0 + sd.dmax; e < e0 + deg; ++e) {
-                const float vv = val[e];
-                const float *x = xa + (col[e] - gs) * CP;
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
-            }
-            const int rB = R + sell_copyB(r, R);
-            XVec<CP> y;
-#pragma unroll
-            for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
-            y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
-        }
-        __syncthreads();
-        float *sw = xa; xa = xb; xb = sw;
-    }
-    chain_epilogue<BWD, NT>(xa, slab, OUT, gs, rows, C, CP, F);
+    chain_epilogue<BWD, NT>(xa, slab, RES, prev_gs, prev_rows, C, CP, F);
 }
 
 // ------------------------------------------------------------------ pack-time slot planning
@@ -1062,70 +1125,111 @@ static int chain_path_override()
     return 0;
 }
 
-#define LAUNCH_SELL(KERN, NTHREADS)                                                                    \
-    do { int rc_ = set_lds(KERN, lds); if (rc_) return rc_;                                            \
-         hipLaunchKernelGGL((KERN), dim3(n_parts), dim3(NTHREADS), lds, st, rp, ci, v, pp, sd, IN, RES, T, tab, F); } while (0)
-
 static int sell_to_dev(const escat_sell *sell, SellDev *sd)
 {
-    if (!sell->val || !sell->lc || !sell->perm || !sell->slice_doff || !sell->slice_poff || !sell->part_slice_ptr)
-        return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
+    if (!sell->val || !sell->lc || !sell->lane_meta) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
     if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
-    sd->val = sell->val; sd->lc = sell->lc; sd->perm = sell->perm; sd->slice_doff = sell->slice_doff;
-    sd->slice_poff = sell->slice_poff; sd->part_slice_ptr = sell->part_slice_ptr; sd->dmax = sell->dmax;
+    if (sell->slices_per_part != 4 && sell->slices_per_part != 8)
+        return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d: must be 4 (parts <= 256 rows) or 8", sell->slices_per_part);
+    sd->val = sell->val; sd->lc = sell->lc; sd->lane_meta = sell->lane_meta; sd->dmax = sell->dmax; sd->nsl = sell->slices_per_part;
+    return ESCAT_OK;
+}
+
+static int cu_count()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+// LDS of a k_chain_sell workgroup: two vectors of two copies, the slab, and the staged input (fwd: x; bwd: a second
+// slab if `want` workgroups per CU still fit -- *early = 1 -- else none)
+static size_t sell_lds_bytes(int C, int CP, int max_rows, int F, bool bwd, int want, int *early)
+{
+    const size_t nv = (size_t)2 * sell_padR(max_rows) * CP;
+    const size_t slab = ((size_t)max_rows * C * F + 3) & ~(size_t)3;
+    const size_t base = (2 * nv + slab) * sizeof(float);
+    if (!bwd) { *early = 1; return base + ((((size_t)max_rows * C + 3) & ~(size_t)3)) * sizeof(float); }
+    const size_t two = base + slab * sizeof(float);
+    if (two * want <= LDS_BUDGET) { *early = 1; return two; }
+    *early = 0;
+    return base;
+}
+
+template <class Op, int NT, bool BWD>
+static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_rows, const SellDev &sd, const float *IN,
+                         float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    if (sd.nsl * 64 != NT) return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d does not match parts of <= %d rows", sd.nsl, max_rows);
+    int early = 0;
+    const int want = Op::MINW == 1 ? 1 : (NT == 512 ? 2 : 4);
+    const size_t lds = sell_lds_bytes(Op::C, Op::CP, max_rows, F, BWD, want, &early);
+    if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "register-resident chain needs %zu B of LDS", lds);
+    auto kern = k_chain_sell<Op, NT, BWD>;
+    int rc = set_lds(kern, lds); if (rc) return rc;
+    static size_t cached_lds = (size_t)-1; static int cached_per_cu = 0;       // per instantiation
+    if (cached_lds != lds) {
+        int per = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, NT, lds) != hipSuccess || per < 1) per = 1;
+        cached_per_cu = per; cached_lds = lds;
+    }
+    const int64_t resident = (int64_t)cached_per_cu * cu_count();
+    const int grid = (int)(n_parts < resident ? n_parts : resident);           // persistent: one wave of workgroups
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ci, v, sd, IN, RES, T, tab, F, n_parts, max_rows, early);
     return ESCAT_OK;
 }
 
 template <int DMAX, bool BWD>
-static int launch_bsr3_sell_d(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
-                              const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+static int launch_bsr3_sell_d(int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd, const float *IN,
+                              float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
-    if (NT <= 256) LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 256, BWD>), 256);
-    else           LAUNCH_SELL((k_chain_bsr3_sell<DMAX, 512, BWD>), 512);
-    return ESCAT_OK;
+    if (max_rows <= 256) return launch_sell_k<OpBsr3<DMAX>, 256, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+    return launch_sell_k<OpBsr3<DMAX>, 512, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
 }
 template <bool BWD>
-static int launch_bsr3_sell(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
-                            size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F,
-                            hipStream_t st)
+static int launch_bsr3_sell(int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd, const float *IN,
+                            float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
     switch (sd.dmax) {
-        case 8:  return launch_bsr3_sell_d<8, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-        case 12: return launch_bsr3_sell_d<12, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-        case 16: return launch_bsr3_sell_d<16, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-        case 22: return launch_bsr3_sell_d<22, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 8:  return launch_bsr3_sell_d<8, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 12: return launch_bsr3_sell_d<12, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 16: return launch_bsr3_sell_d<16, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 20: return launch_bsr3_sell_d<20, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 22: return launch_bsr3_sell_d<22, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
     }
-    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: BSR-3 packs must use 8, 12, 16 or 22", sd.dmax);
+    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: BSR-3 packs must use 8, 12, 16, 20 or 22", sd.dmax);
 }
 
 template <int C, int DMAX, bool BWD>
-static int launch_csr_sell_d(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts, size_t lds,
-                             const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+static int launch_csr_sell_d(int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd, const float *IN,
+                             float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
-    if (NT <= 256) LAUNCH_SELL((k_chain_csr_sell<C, DMAX, 256, BWD>), 256);
-    else           LAUNCH_SELL((k_chain_csr_sell<C, DMAX, 512, BWD>), 512);
-    return ESCAT_OK;
+    if (max_rows <= 256) return launch_sell_k<OpCsr<C, DMAX>, 256, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+    return launch_sell_k<OpCsr<C, DMAX>, 512, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
 }
 template <int C, bool BWD>
-static int launch_csr_sell_c(int NT, const int *rp, const int *ci, const float *v, const int *pp, int n_parts,
-                             size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab, int F,
-                             hipStream_t st)
+static int launch_csr_sell_c(int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd, const float *IN,
+                             float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
     switch (sd.dmax) {
-        case 8:  return launch_csr_sell_d<C, 8, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-        case 16: return launch_csr_sell_d<C, 16, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-        case 24: return launch_csr_sell_d<C, 24, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
-        case 32: return launch_csr_sell_d<C, 32, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+        case 8:  return launch_csr_sell_d<C, 8, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 16: return launch_csr_sell_d<C, 16, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 24: return launch_csr_sell_d<C, 24, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 32: return launch_csr_sell_d<C, 32, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
     }
     return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: CSR packs must use 8, 16, 24 or 32", sd.dmax);
 }
 template <bool BWD>
-static int launch_csr_sell(int C, int NT, const int *rp, const int *ci, const float *v, const int *pp,
-                           int n_parts, size_t lds, const SellDev &sd, const float *IN, float *RES, int T, const EvTable &tab,
-                           int F, hipStream_t st)
+static int launch_csr_sell(int C, int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd,
+                           const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
     switch (C) {
-#define CASE(c) case c: return launch_csr_sell_c<c, BWD>(NT, rp, ci, v, pp, n_parts, lds, sd, IN, RES, T, tab, F, st);
+#define CASE(c) case c: return launch_csr_sell_c<c, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     }
@@ -1154,12 +1258,12 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
         const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
         if (lds <= LDS_BUDGET) {
             const int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
-            const size_t nv = (size_t)2 * sell_padR(max_part_rows) * CP;
-            const size_t lds_s = (2 * nv + (size_t)max_part_rows * C * F) * sizeof(float);
+            int early_ = 0;
+            const size_t lds_s = sell_lds_bytes(C, CP, max_part_rows, F, BWD, max_part_rows <= 256 ? 4 : 2, &early_);
             if (max_part_rows <= 512 && sell && force != 2 && lds_s <= LDS_BUDGET) {
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
-                rc = launch_csr_sell<BWD>(C, max_part_rows, rowptr, col, val, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
+                rc = launch_csr_sell<BWD>(C, max_part_rows, col, val, n_parts, sd, IN, RES, T, tab, F, st);
             } else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
             if (rc) return rc;
@@ -1241,11 +1345,12 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
     const int force = chain_path_override();
     if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3) {
         const size_t lds = (size_t)max_part_rows * 3 * (2 + F) * sizeof(float);
-        const size_t lds_s = ((size_t)2 * 2 * sell_padR(max_part_rows) * 4 + (size_t)max_part_rows * 3 * F) * sizeof(float);
+        int early_ = 0;
+        const size_t lds_s = sell_lds_bytes(3, 4, max_part_rows, F, BWD, 1, &early_);
         if (lds <= LDS_BUDGET && lds_s <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
-            rc = launch_bsr3_sell<BWD>(max_part_rows, rowptr, col, blk, part_ptr, n_parts, lds_s, sd, IN, RES, T, tab, F, st);
+            rc = launch_bsr3_sell<BWD>(max_part_rows, col, blk, n_parts, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_bsr3_sell");
             return ESCAT_OK;

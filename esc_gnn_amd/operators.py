@@ -71,7 +71,10 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
 
 
 SELL_MAX_PART_ROWS = 512
-_SELL_DMAX = {1: (8, 16, 24, 32), 9: (8, 12, 16, 22)}     # register capacities the kernels are instantiated for
+_SELL_DMAX = {1: (8, 16, 24, 32), 9: (8, 12, 16, 20, 22)}     # register capacities the kernels are instantiated for
+# rows longer than the capacity stream their tail from L2 every step (slow for their whole workgroup), but the largest
+# BSR-3 capacity leaves the kernel short of registers: accept a capacity that leaves at most this fraction of rows a tail
+_SELL_TAIL_ROWS = 5e-5
 
 
 def _cumsum0(t):
@@ -111,7 +114,10 @@ class Sell:
         dev = form.rowptr.device
         V = 9 if form.val.dim() == 3 else 1
         caps = _SELL_DMAX[V]
-        self.dmax = next((c for c in caps if c >= form.max_row_nnz), caps[-1])
+        deg_all = (form.rowptr[1:] - form.rowptr[:-1]).long()
+        hist = torch.bincount(deg_all.clamp(max=caps[-1] + 1), minlength=caps[-1] + 2).cumsum(0)
+        allowed = int(_SELL_TAIL_ROWS * form.n)
+        self.dmax = next((c for c in caps if form.n - int(hist[c]) <= allowed), caps[-1])
         dmax = self.dmax
         n, nnz = form.n, form.nnz
         rp = form.rowptr.long()
@@ -122,9 +128,12 @@ class Sell:
         part_of_row = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_rows)
         dcl = deg.clamp(max=dmax)
         order = torch.argsort(part_of_row * (dmax + 1) + (dmax - dcl), stable=True)     # rows in lane order
-        part_slices = (part_rows + 63) // 64
+        # every part owns nsl slices (= waves of the workgroup that serves it); trailing ones may be empty
+        nsl = 4 if form.max_part_rows <= 256 else 8
+        self.slices_per_part = nsl
+        part_slices = torch.full((n_parts,), nsl, dtype=torch.int64, device=dev)
         psp = _cumsum0(part_slices)
-        n_slices = int(psp[-1])
+        n_slices = n_parts * nsl
         # sorted position i (row order[i], part part_of_row[i]) -> its lane
         slot0 = psp[part_of_row] * 64 + (torch.arange(n, device=dev) - pp[part_of_row])
         perm = torch.full((n_slices * 64,), -1, dtype=torch.int32, device=dev)
@@ -132,7 +141,7 @@ class Sell:
         slot_cnt = torch.zeros(n_slices * 64, dtype=torch.int64, device=dev)
         slot_cnt[slot0] = dcl[order]
         w = slot_cnt.view(n_slices, 64).max(dim=1).values
-        doff, poff = _cumsum0(w), _cumsum0((w + 1) // 2)
+        doff, poff = _cumsum0(w), _cumsum0(((w + 3) // 4) * 2)      # LDS-row pairs cover w rounded up to 4 slots
         row_slot0 = torch.empty(n, dtype=torch.int64, device=dev)
         row_slot0[order] = slot0
         slice_part = torch.repeat_interleave(torch.arange(n_parts, device=dev), part_slices)
@@ -155,38 +164,55 @@ class Sell:
         drow = doff[s_k] + slot_of_e[e_k].long()
         total_d, total_p = int(doff[-1]), int(poff[-1])
         if V == 9:
-            val = torch.zeros(max(total_d, 1) * 576, dtype=torch.float32, device=dev)
+            val = torch.zeros((total_d + 1) * 576, dtype=torch.float32, device=dev)     # + one padding slot (empty slices read it)
             src = form.val.reshape(nnz, 9)[e_k]
             for q in range(9):
                 dst = drow * 576 + (q // 4) * 256 + (lane * 4 + q % 4 if q < 8 else lane)
                 val[dst] = src[:, q]
         else:
-            val = torch.zeros(max(total_d, 1) * 64, dtype=torch.float32, device=dev)
+            val = torch.zeros((total_d + 1) * 64, dtype=torch.float32, device=dev)
             val[drow * 64 + lane] = form.val[e_k]
         # LDS rows, one int per (slice, slot, lane); slots past a row's end point at the part's all-zero LDS row
         zc = part_rows[slice_part]                                                        # per slice
         slice_of_drow = torch.repeat_interleave(torch.arange(n_slices, device=dev), w)
         lcu = zc[slice_of_drow].repeat_interleave(64)                                     # (total_d*64,)
         lcu[drow * 64 + lane] = lc_of_e[e_k].long()
-        npair = (w + 1) // 2
+        npair = ((w + 3) // 4) * 2
         slice_of_pair = torch.repeat_interleave(torch.arange(n_slices, device=dev), npair)
         j2 = torch.arange(total_p, device=dev) - poff[slice_of_pair]
-        d_lo = doff[slice_of_pair] + 2 * j2
+        has_lo = (2 * j2) < w[slice_of_pair]
         has_hi = (2 * j2 + 1) < w[slice_of_pair]
+        d_first = doff[slice_of_pair]
         lanes = torch.arange(64, device=dev)
-        lo = lcu[(d_lo[:, None] * 64 + lanes[None, :]).reshape(-1)].view(-1, 64) if total_p else lcu.view(0, 64)
-        d_hi = torch.where(has_hi, d_lo + 1, d_lo)
-        hi = lcu[(d_hi[:, None] * 64 + lanes[None, :]).reshape(-1)].view(-1, 64) if total_p else lo
-        hi = torch.where(has_hi[:, None], hi, zc[slice_of_pair][:, None].expand(-1, 64))
-        lc = (lo | (hi << 16)).reshape(-1)
-        if total_p == 0:
-            lc = torch.zeros(64, dtype=torch.int64, device=dev)
+        zrow = zc[slice_of_pair][:, None].expand(-1, 64)
+
+        def rows_of(d_abs, has):
+            d_safe = torch.where(has, d_abs, d_first).clamp(max=max(total_d - 1, 0))
+            got = lcu[(d_safe[:, None] * 64 + lanes[None, :]).reshape(-1)].view(-1, 64)
+            return torch.where(has[:, None], got, zrow)
+        if total_p and total_d:
+            lo, hi = rows_of(d_first + 2 * j2, has_lo), rows_of(d_first + 2 * j2 + 1, has_hi)
+        else:
+            lo = hi = torch.zeros((0, 64), dtype=torch.int64, device=dev)
+        lc = torch.cat([(lo | (hi << 16)).reshape(-1), torch.zeros(64, dtype=torch.int64, device=dev)])   # + padding pair
+        # per-lane start-up record: {row | tail_n << 10, tail_e0, slice word}
+        lm = torch.zeros((n_slices * 64, 3), dtype=torch.int64, device=dev)
+        lm[:, 0] = 0x3ff
+        tail_n = (deg - dmax).clamp(min=0)
+        rows_idx = torch.arange(n, device=dev)
+        lm[row_slot0, 0] = (rows_idx - pp[part_of_row]) | (tail_n << 10)
+        lm[row_slot0, 1] = rp[:-1] + dmax
+        sw = lm[:, 2].view(n_slices, 64)
+        sw[:, 0], sw[:, 1], sw[:, 2] = doff[:-1], poff[:-1], w
+        sw[:, 3], sw[:, 4] = pp[slice_part], part_rows[slice_part]
+        if int(tail_n.max() if n else 0) >= (1 << 21) or form.max_part_rows >= 0x3ff:
+            raise ValueError("escat: part too large for the SELL lane record")
         self.val = val
         self.lc = lc.to(torch.int32)          # bit pattern of the packed uint32 pairs (values < 2^26 here)
         self.perm = perm
+        self.lane_meta = lm.to(torch.int32).contiguous()
         self.slice_doff = doff.to(torch.int32)
         self.slice_poff = poff.to(torch.int32)
-        self.part_slice_ptr = psp.to(torch.int32)
         self.n_slices = n_slices
         self.pad_ratio = float(total_d * 64) / max(float(dcl.sum()), 1.0)
         self.slot_of_e, self.lc_of_e = slot_of_e, lc_of_e      # kept for tests / diagnostics (8 B per entry)

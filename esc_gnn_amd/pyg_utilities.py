@@ -36,12 +36,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else 0) if t is not None else ctypes.c_void_p(0)
 
 
-def chain_lds_bytes(max_part_rows: int, C: int, F: int, bsr3: bool) -> int:
-    """LDS a register-resident chain workgroup needs: two ping-pong vectors of two copies each + the output slab."""
+def chain_lds_bytes(max_part_rows: int, C: int, F: int, bsr3: bool, backward: bool = False) -> int:
+    """LDS a register-resident chain workgroup needs at least: two ping-pong vectors of two copies each, the output
+    slab, and (forward) the staged input.  (Backward adds a second slab when it fits -- decided in the library.)"""
     from .operators import sell_pad_rows
     CP = 4 if bsr3 else (1 if C == 1 else 2 if C == 2 else 4 if C <= 4 else 8)
     cw = 3 if bsr3 else C
-    return (2 * 2 * sell_pad_rows(max_part_rows) * CP + max_part_rows * cw * F) * 4
+    slab = (max_part_rows * cw * F + 3) & ~3
+    stage = 0 if backward else (max_part_rows * cw + 3) & ~3
+    return (2 * 2 * sell_pad_rows(max_part_rows) * CP + slab + stage) * 4
 
 
 def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool) -> torch.Tensor:
@@ -54,7 +57,7 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
     form = (op.bsr3_t() if backward else op.bsr3()) if use_bsr else (op.csr_t() if backward else op.csr())
     rows_per = 3 if use_bsr else 1
     out = torch.empty((n, C) if backward else (n, C, F), dtype=torch.float32, device=dev)
-    lds = chain_lds_bytes(form.max_part_rows, C, F, use_bsr)
+    lds = chain_lds_bytes(form.max_part_rows, C, F, use_bsr, backward)
     path = os.environ.get("ESCAT_CHAIN_PATH", "")
     fused = form.n_parts > 0 and lds <= LDS_BUDGET and not path.startswith("multi")
     ws = None
@@ -66,17 +69,16 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
         sell = None
     sell_ref = ctypes.c_void_p(0)
     if sell is not None:
-        sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.perm.data_ptr(),
-                                     sell.slice_doff.data_ptr(), sell.slice_poff.data_ptr(),
-                                     sell.part_slice_ptr.data_ptr(), sell.dmax, sell.n_slices, 0, 0)
+        sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(),
+                                     sell.dmax, sell.n_slices, sell.slices_per_part, 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
         # cfg3 it does not beat the lane-group step kernel (0.61 vs 0.53 ms/step on a locality-sorted cloud, equal on
         # random node order where the x gather dominates), so the default multi-launch path stays unpacked.
         sg = form.sell_global()
-        sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0,
-                                     sg.n_slices, 1, sg.col32.data_ptr())
+        sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, 0, 0, sg.n_slices, 0, 0,
+                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr())
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)

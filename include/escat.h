@@ -60,9 +60,11 @@ typedef struct { int32_t step, slot, sign, chan; } escat_event;
 
 /* Packed "SELL-64" copy of a CSR / BSR-3 operator for the register-resident
  * chain kernels (all members are device pointers; the struct itself lives on
- * the host).  Inside each part rows are sorted by length, descending, and cut
- * into slices of 64 rows (one wave); slice s keeps the first
- * w_s = min(longest row of the slice, dmax) entries of each row, slot-major:
+ * the host).  Every part owns slices_per_part slices (4 if no part has more than
+ * 256 rows, else 8; trailing slices of a part may be empty).  Inside each part
+ * rows are sorted by length, descending, and cut into slices of 64 rows (one
+ * wave); slice s keeps the first w_s = min(longest row of the slice, dmax)
+ * entries of each row, slot-major:
  *   CSR   val[(doff_s + d)*64 + lane]
  *   BSR-3 val[(doff_s + d)*576 + {lane*4+0..3 | 256+lane*4+0..3 | 512+lane}]
  *         = block floats 0-3 | 4-7 | 8
@@ -70,30 +72,36 @@ typedef struct { int32_t step, slot, sign, chan; } escat_event;
  *         with local column a (= column - first row of the part) is a (copy A of the vector) or R + copyB(a)
  *         (copy B; R = rows of the part + 1 rounded up to 16, copyB rotates bits 0-3 of a to the top of its
  *         256-row block), as chosen by escat_sell_plan_slots; slots past a row's end hold `rows` (the zero row)
- * with doff_s = slice_doff[s], poff_s = slice_poff[s] (prefix sums of w_s and
- * ceil(w_s/2)), perm[s*64 + lane] = local row served by that lane (-1: none),
- * part_slice_ptr[p] = first slice of part p.  Entries beyond dmax stay in the
- * CSR / BSR-3 arrays and are streamed.  dmax: 8/16/24/32 (CSR), 8/12/16/22 (BSR-3).
- * esc_gnn_amd/operators.py builds it (torch index ops, once per operator). */
+ *         (the pairs of a slice cover w_s rounded up to a multiple of 4 slots)
+ * with doff_s, poff_s = prefix sums of w_s and 2*ceil(w_s/4) over all slices, and
+ *   lane_meta[(s*64 + lane)*3 + 0] = local row served by the lane (0x3ff: none) | tail_n << 10
+ *   lane_meta[(s*64 + lane)*3 + 1] = tail_e0: the row's entries [tail_e0, tail_e0 + tail_n) of the CSR / BSR-3
+ *                                    arrays lie beyond dmax and are streamed every step
+ *   lane_meta[(s*64 + lane)*3 + 2] = slice word: lanes 0..4 hold doff_s, poff_s, w_s, first row of the part,
+ *                                    rows of the part (one 12-byte load per lane starts a part)
+ * val and lc end with one padding slot / pair (the kernels read it for empty slices).
+ * dmax: 8/16/24/32 (CSR), 8/12/16/20/22 (BSR-3).
+ * esc_gnn_amd/operators.py builds it (torch index ops + escat_sell_plan_slots, once per operator). */
 typedef struct {
     const float    *val;
     const uint32_t *lc;
-    const int32_t  *perm;
-    const int32_t  *slice_doff;
-    const int32_t  *slice_poff;
-    const int32_t  *part_slice_ptr;
+    const int32_t  *lane_meta;
     int32_t         dmax;
     int32_t         n_slices;
+    int32_t         slices_per_part;
     int32_t         reserved;       /* 0 */
-    const int32_t  *col32;          /* NULL, or: one GLOBAL (block) column per slot, [(doff_s + d)*64 + lane], -1 = padding.
-                                       Then the pack covers the whole operator (slices of 64 rows sorted by length inside
-                                       windows, perm = global row, lc / slice_poff / part_slice_ptr unused, no dmax cap)
-                                       and drives the multi-launch path for graphs that do not fit LDS (BSR-3 only). */
+    /* whole-operator variant for the multi-launch path of graphs that do not fit LDS (BSR-3 only), selected by
+     * col32 != NULL: slices of 64 rows sorted by length inside windows, no dmax cap; val as above,
+     * col32[(doff_s + d)*64 + lane] = GLOBAL block column (-1 = padding), perm[s*64 + lane] = global row (-1: none),
+     * slice_doff[s] = doff_s (n_slices + 1 entries); lc / lane_meta unused. */
+    const int32_t  *col32;
+    const int32_t  *perm;
+    const int32_t  *slice_doff;
 } escat_sell;
 
 /* Pack-time planning for escat_sell: for every entry e among the first dmax of its row, the slot (column of its
  * slice) and the LDS row (vector copy A or B) it will use, chosen so that the 16 lanes of each ds_read_b128 lane
- * group land on distinct 16-byte bank slots where possible.  slice_part[s] = part of slice s; slot_of_e must be
+ * group land on distinct 16-byte bank slots where possible.  slice_part[s] = part of slice s, perm[s*64 + lane] = local row of the lane (-1: none); slot_of_e must be
  * pre-filled with -1 (entries beyond dmax keep it). */
 int escat_sell_plan_slots(const int32_t *rowptr, const int32_t *col, const int32_t *part_ptr,
                           const int32_t *slice_part, const int32_t *perm, int n_slices, int dmax,

@@ -301,6 +301,48 @@ def test_sell_slot_plan_is_a_valid_permutation_and_cuts_conflicts():
     assert c_plan < 0.8 * c_nat, (c_plan, c_nat)
 
 
+def _concat_batches(bs):
+    """block-diagonal concatenation of synthetic batches (ragged graph sizes)."""
+    rowptr, col, pval, blk, pos = [np.zeros(1, np.int32)], [], [], [], []
+    N = nnz = 0
+    for b in bs:
+        rowptr.append(b["rowptr"][1:] + nnz); col.append(b["col"] + N)
+        pval.append(b["pval"]); blk.append(b["blk"]); pos.append(b["pos"])
+        N += b["N"]; nnz += b["nnz"]
+    return dict(rowptr=np.concatenate(rowptr).astype(np.int32), col=np.concatenate(col).astype(np.int32),
+                pval=np.concatenate(pval), blk=np.concatenate(blk), pos=np.concatenate(pos), N=N, nnz=nnz)
+
+
+def test_persistent_pipeline_many_ragged_parts():
+    """more parts than resident workgroups: every workgroup walks several parts of different sizes (metadata prefetch,
+    staged-input DMA, operator refill under the previous epilogue); P backward takes the single-slab branch (two slabs
+    of 500 x 3 x 6 floats do not fit twice per CU), Q backward the double-slab one."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    dev = _dev()
+    b = _concat_batches([synthetic.ellipsoid_batch(300, 500, 8, seed=1), synthetic.ellipsoid_batch(300, 333, 8, seed=2),
+                         synthetic.ellipsoid_batch(320, 420, 8, seed=3)])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    assert opP.csr().n_parts == 920 and opP.csr().max_part_rows == 500
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(b["N"], 3, generator=g)
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    for kw in (dict(J=3), dict(scales_type="custom", diffusion_scales=torch.tensor([0]))):     # T = 8 and T = 0
+        plan = plan_chain(**kw)
+        ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+        gP = torch.randn(b["N"], 3, plan.F, generator=g)
+        gQ = torch.randn(3 * b["N"], 1, plan.F, generator=g)
+        xg = x.to(dev).requires_grad_(True)
+        W = get_Batch_Wjxs(xg, opP, **kw); W.backward(gP.to(dev))
+        xq = xv.to(dev).requires_grad_(True)
+        Wq = get_Batch_Wjxs(xq, opQ, **kw); Wq.backward(gQ.to(dev))
+        _close(W, co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F))
+        _close(Wq, co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F))
+        _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T), rtol=2e-5)
+        _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=2e-5)
+
+
 def test_register_path_long_rows_and_small_parts():
     """rows longer than the register capacity (DMAX) take the streamed tail; parts of many tiny graphs."""
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""debug: wall-clock stamps of the phases of every part in the persistent chain kernel.
+needs `make -C esc_gnn_amd/csrc stamps` (libescat_stamps.so, built with -DESCAT_STAMPS).
+usage: python tools/stamps.py [P|Q] [fwd|bwd]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from esc_gnn_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libescat_stamps.so")
+from esc_gnn_amd import synthetic
+which = sys.argv[1] if len(sys.argv) > 1 else "Q"
+bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
+G = 4096
+b = synthetic.ellipsoid_batch(G, 500, 10, seed=457893, workers=8)
+import torch
+from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(a).to(dev)
+if which == "Q":
+    op = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"]); x = t(b["pos"]).reshape(-1, 1).clone()
+else:
+    op = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"]); x = t(b["pos"]).clone()
+_lib.load()
+raw = ctypes.CDLL(_lib.LIB_PATH)
+us = lambda a: a / 100.0      # wall_clock64: 100 MHz
+for J in (0, 4):
+    def run():
+        xx = x.clone().requires_grad_(bwd)
+        W = get_Batch_Wjxs(xx, op, J=J)
+        if bwd:
+            g = torch.ones_like(W)
+            torch.cuda.synchronize()
+            return lambda: W.backward(g)
+        return None
+    for _ in range(2):
+        f = run(); f and f()
+    st = torch.zeros(G * 8, dtype=torch.int64, device=dev)
+    f = run()
+    raw.escat_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))
+    if f: f()
+    else: get_Batch_Wjxs(x, op, J=J)
+    torch.cuda.synchronize()
+    raw.escat_debug_set_stamps(ctypes.c_void_p(0))
+    s = st.cpu().numpy().reshape(G, 8).astype(np.int64)
+    names = ["operator loads issued", "previous epilogue issued", "input wait + barrier", "prologue", "step 1 (waits for the operator)",
+             "steps 2..T", "post-step wait"]
+    print(f"== {which} {'bwd' if bwd else 'fwd'} J={J}: span {us(s[:, 6].max() - s[:, 0].min()):.1f} us")
+    for k, nm in enumerate(names):
+        a, bb = s[:, k], s[:, k + 1]
+        ok = (a > 0) & (bb > 0)
+        d = us(bb[ok] - a[ok])
+        print(f"   {nm:34s} +{d.mean():7.2f} us (p10 {np.percentile(d, 10):6.2f}, p90 {np.percentile(d, 90):6.2f})")
+    ok = s[:, 7] > 0
+    print(f"   part total (0 -> 7)                {us(s[ok, 7] - s[ok, 0]).mean():7.2f} us")
