@@ -51,7 +51,7 @@ def compulsory_bytes_vector(N, nnz, F):
     return 38 * nnz + 4 * (N + 1) + 12 * N + 12 * N * F
 
 
-def measured_traffic(args, kernel_key):
+def measured_traffic(args, kernel_key, kernel_end=""):
     """HBM bytes per launch from the committed PMC summary (profiles/hbm_traffic.json), if it is for this workload."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
@@ -61,7 +61,7 @@ def measured_traffic(args, kernel_key):
     if (c.get("graphs"), c.get("nodes"), c.get("k"), c.get("J")) != (args.graphs, args.nodes, args.k, args.J):
         return None
     for name, v in t.get("kernels", {}).items():
-        if name.startswith(kernel_key):
+        if name.startswith(kernel_key) and name.endswith(kernel_end):
             return v.get("hbm_bytes_per_launch_corrected")
     return None
 
@@ -182,7 +182,7 @@ def main():
         bytes_p = alg_bytes_scalar(N, nnz, C, T, F)
         achieved = bytes_q / (per["Q_fwd"] * 1e-3) / 1e9
         comp_q = compulsory_bytes_vector(N, nnz, F)
-        traffic = measured_traffic(args, "k_chain_bsr3_sell<22, 512, false>")
+        traffic = measured_traffic(args, "k_chain_sell<OpBsr3", ", false>")
         out = {
             "metric": "graphs/sec for P+Q scattering fwd+bwd (J=4)",
             "value": args.graphs * world * args.steps / dt,
@@ -195,7 +195,7 @@ def main():
                                    f"P (CSR, C=3) + Q (BSR-3) dyadic J={args.J} + lowpass, fwd+bwd",
                        "graphs_per_gpu": args.graphs, "nodes_per_graph": args.nodes, "k": args.k, "J": args.J,
                        "N": N, "nnz_P": nnz, "T": T, "F": F, "parallelism": f"dp{world} (graph shards, no data-path collective)"},
-            "roofline": {"bound": "hbm", "kernel": "k_chain_bsr3_sell (Q chain forward)",
+            "roofline": {"bound": "hbm", "kernel": "k_chain_sell<OpBsr3<..>, 512, false> (Q chain forward)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_q, "ms_per_launch": per["Q_fwd"],

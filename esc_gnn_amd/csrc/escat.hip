@@ -526,7 +526,8 @@ __device__ __forceinline__ float apply_events(const EvTable &tab, int q0, int q1
 // dmax) entries slot-major,
 //   CSR   val[(doff_s + d) * 64 + lane]
 //   BSR-3 val[(doff_s + d) * 576 + {0: lane*4 + 0..3 | 256: lane*4 + 0..3 | 512: lane}]
-//         (the 9 floats of a block as two float4 pieces and one scalar piece)
+//         (the 9 floats of a block as two float4 pieces and one scalar piece:
+//          b00 b10 b01 b11 | b02 b12 b20 b21 | b22)
 //   lc[(poff_s + d/2) * 64 + lane] = LDS row of slot d | LDS row of slot d+1 << 16, for d < w_s rounded up to 4
 // so that every load of a wave is one fully coalesced 256-B or 1-KiB access, and the sort makes w_s the length of
 // (nearly) every row of the slice: few idle slots.  Slots past a row's end hold value 0 and LDS row = rows of the part
@@ -541,18 +542,22 @@ struct SellDev {
     int dmax, nsl;
 };
 
-#define SLOT_GROUP 4      // slots issued together: their LDS gathers are in flight at once
+#define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
+#define GATHER_AHEAD 3     // LDS gathers in flight ahead of the FMAs
 
 // debug build only (-DESCAT_STAMPS, see tools/stamps.py): wall-clock stamps of the phases of every part
 #ifdef ESCAT_STAMPS
 __device__ unsigned long long *g_stamps = nullptr;
-#define STAMP(part, i) do { if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)(part) * 8 + (i)] = wall_clock64(); } while (0)
+#define STAMP(part, i) do { if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)(part) * 16 + (i)] = wall_clock64(); } while (0)
+#define STAMPW(part, i, tid) do { if (g_stamps && threadIdx.x == (tid)) g_stamps[(size_t)(part) * 16 + (i)] = wall_clock64(); } while (0)
 extern "C" int escat_debug_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
 #else
 #define STAMP(part, i)
+#define STAMPW(part, i, tid)
 #endif
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int CP> struct XVec;
@@ -579,8 +584,11 @@ template <> struct XVec<8> { float v[8];
 //   tail(...)                   entries beyond dmax, streamed
 template <int DMAX> struct OpBsr3 {
     static constexpr int C = 3, CP = 4, MINW = 1;
-    // a block's 9 floats as the three pieces they are loaded in
-    float4 b0[DMAX], b1[DMAX];
+    // a block's 9 floats as the three pieces they are loaded in, ordered for packed fp32 math:
+    //   b0 = (b00, b10, b01, b11)   b1 = (b02, b12, b20, b21)   b2 = b22       (bij = row i, column j of the block)
+    // so that (y0, y1) += (b0j, b1j) * xj is one v_pk_fma_f32 per column j (xj broadcast by op_sel) and
+    // (b20, b21) * (x0, x1) another: 5 VALU instructions per block instead of 9.
+    vf4 b0[DMAX], b1[DMAX];
     float b2[DMAX];
     unsigned lc[(DMAX + 1) / 2];
     // Every slot register is written by exactly one UNCONDITIONAL load per part: a slot past the slice's width re-reads
@@ -596,43 +604,55 @@ template <int DMAX> struct OpBsr3 {
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
             const int dd = d < wl ? d : wl;       // wave-uniform
-            b0[d] = *reinterpret_cast<const float4 *>(vb + dd * 576 + lane * 4);
-            b1[d] = *reinterpret_cast<const float4 *>(vb + dd * 576 + 256 + lane * 4);
+            b0[d] = *reinterpret_cast<const vf4 *>(vb + dd * 576 + lane * 4);
+            b1[d] = *reinterpret_cast<const vf4 *>(vb + dd * 576 + 256 + lane * 4);
             b2[d] = vb[dd * 576 + 512 + lane];
         }
 #pragma unroll
         for (int j2 = 0; j2 < (DMAX + 1) / 2; ++j2)
             lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
     }
+    // One step of this lane's row.  gather() dispatches (wave-uniform) on the slice's width, rounded up to 2, to a
+    // straight-line body for exactly that many slots: the LDS gathers run GATHER_AHEAD slots ahead of the FMAs in a ring
+    // of registers, so a wave always has gathers in flight (two waves per SIMD cannot hide LDS latency by themselves),
+    // and without branches in the body the compiler can count them (s_waitcnt lgkmcnt(N), not 0).  The odd slot of a
+    // rounded-up width re-reads a real block against the all-zero row.
+    __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    template <int W>
+    __device__ __forceinline__ void gather_w(const float *xa, vf2 &a01, vf2 &t2, float &a2) const
+    {
+        vf4 xv[GATHER_AHEAD + 1];
+#pragma unroll
+        for (int d = 0; d < GATHER_AHEAD && d < W; ++d) xv[d] = *reinterpret_cast<const vf4 *>(xa + row_of(d) * 4u);   // a row is 4 floats
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            if (d + GATHER_AHEAD < W)
+                xv[(d + GATHER_AHEAD) % (GATHER_AHEAD + 1)] = *reinterpret_cast<const vf4 *>(xa + row_of(d + GATHER_AHEAD) * 4u);
+            const vf4 x = xv[d % (GATHER_AHEAD + 1)];
+            a01 = __builtin_elementwise_fma(b0[d].xy, x.xx, a01);
+            a01 = __builtin_elementwise_fma(b0[d].zw, x.yy, a01);
+            a01 = __builtin_elementwise_fma(b1[d].xy, x.zz, a01);
+            t2 = __builtin_elementwise_fma(b1[d].zw, x.xy, t2);
+            a2 = fmaf(b2[d], x.z, a2);
+            // keep the pad lane live: otherwise the gather is narrowed to ds_read_b96 (8 LDS cycles, 8-lane groups on
+            // 32 banks) instead of ds_read_b128 (4 cycles, the 16-lane groups the pack is planned for)
+            asm volatile("" :: "v"(x.w));
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, vf2 &a01, vf2 &t2, float &a2) const
+    {
+        if constexpr (W <= DMAX) {
+            if (w2 == W / 2) gather_w<W>(xa, a01, t2, a2);
+            else dispatch<W + 2>(w2, xa, a01, t2, a2);
+        }
+    }
     __device__ __forceinline__ void gather(const float *xa, int w, float (&a)[3]) const
     {
-#pragma unroll
-        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
-            if (d0 < w) {                         // wave-uniform: slice width, in groups
-                float4 xv[SLOT_GROUP];
-#pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) {               // lc holds LDS rows; a row is 4 floats
-                        const unsigned row = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);
-                        xv[g] = *reinterpret_cast<const float4 *>(xa + row * 4u);
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) {
-                        const float x0 = xv[g].x, x1 = xv[g].y, x2 = xv[g].z;
-                        a[0] = fmaf(b0[d].x, x0, a[0]); a[0] = fmaf(b0[d].y, x1, a[0]); a[0] = fmaf(b0[d].z, x2, a[0]);
-                        a[1] = fmaf(b0[d].w, x0, a[1]); a[1] = fmaf(b1[d].x, x1, a[1]); a[1] = fmaf(b1[d].y, x2, a[1]);
-                        a[2] = fmaf(b1[d].z, x0, a[2]); a[2] = fmaf(b1[d].w, x1, a[2]); a[2] = fmaf(b2[d], x2, a[2]);
-                        // keep the pad lane live: otherwise the gather is narrowed to ds_read_b96 (8 LDS cycles, 8-lane
-                        // groups on 32 banks) instead of ds_read_b128 (4 cycles, the 16-lane groups the pack is planned for)
-                        asm volatile("" :: "v"(xv[g].w));
-                    }
-                }
-            }
-        }
+        vf2 a01 = {0.f, 0.f}, t2 = {0.f, 0.f};    // (y0, y1) and the two-column partial sums of y2
+        float a2 = 0.f;
+        dispatch<2>((w + 1) >> 1, xa, a01, t2, a2);
+        a[0] += a01.x; a[1] += a01.y; a[2] += a2 + (t2.x + t2.y);
     }
     static __device__ __forceinline__ void tail(const float *__restrict__ blk, const int *__restrict__ col, int e0, int n,
                                                 int gs, const float *xa, float (&a)[3])
@@ -664,29 +684,31 @@ template <int CC, int DMAX> struct OpCsr {
         for (int j2 = 0; j2 < DMAX / 2; ++j2)
             lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];     // LDS rows, two per register
     }
-    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[CC]) const
+    __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    template <int W>
+    __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[CC]) const      // see OpBsr3::gather_w
     {
+        XVec<CP> xv[GATHER_AHEAD + 1];
 #pragma unroll
-        for (int d0 = 0; d0 < DMAX; d0 += SLOT_GROUP) {
-            if (d0 < w) {
-                XVec<CP> xv[SLOT_GROUP];
+        for (int d = 0; d < GATHER_AHEAD && d < W; ++d) xv[d].load(xa + row_of(d) * (unsigned)CP);
 #pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) xv[g].load(xa + ((d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu)) * (unsigned)CP);
-                }
+        for (int d = 0; d < W; ++d) {
+            if (d + GATHER_AHEAD < W) xv[(d + GATHER_AHEAD) % (GATHER_AHEAD + 1)].load(xa + row_of(d + GATHER_AHEAD) * (unsigned)CP);
+            const XVec<CP> &x = xv[d % (GATHER_AHEAD + 1)];
 #pragma unroll
-                for (int g = 0; g < SLOT_GROUP; ++g) {
-                    const int d = d0 + g;
-                    if (d < DMAX) {
-#pragma unroll
-                        for (int c = 0; c < CC; ++c) acc[c] = fmaf(v[d], xv[g].v[c], acc[c]);
-                        if (CC % 4 == 3) asm volatile("" :: "v"(xv[g].v[CP - 1]));   // 12-B tail: keep it a ds_read_b128, not b96
-                    }
-                }
-            }
+            for (int c = 0; c < CC; ++c) acc[c] = fmaf(v[d], x.v[c], acc[c]);
+            if (CC % 4 == 3) asm volatile("" :: "v"(x.v[CP - 1]));   // 12-B tail: keep it a ds_read_b128, not b96
         }
     }
+    template <int W>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, float (&acc)[CC]) const
+    {
+        if constexpr (W <= DMAX) {
+            if (w2 == W / 2) gather_w<W>(xa, acc);
+            else dispatch<W + 2>(w2, xa, acc);
+        }
+    }
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[CC]) const { dispatch<2>((w + 1) >> 1, xa, acc); }
     static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
                                                 int gs, const float *xa, float (&acc)[CC])
     {
@@ -837,7 +859,13 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
             float acc[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#ifdef ESCAT_STAMPS
+            if (t == 5) { STAMPW(part, 8, 0); STAMPW(part, 12, NT - 64); }
+#endif
             op.gather(xa, w, acc);
+#ifdef ESCAT_STAMPS
+            if (t == 5) { STAMPW(part, 9, 0); STAMPW(part, 13, NT - 64); }
+#endif
             if (own) {
                 if (tn) Op::tail(val, col, te0, tn, gs, xa, acc);
                 XVec<CP> y;
@@ -847,10 +875,14 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
                 y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
             }
+#ifdef ESCAT_STAMPS
+            if (t == 5) { STAMPW(part, 10, 0); STAMPW(part, 14, NT - 64); }
+#endif
             __syncthreads();
             float *tmp = xa; xa = xb; xb = tmp;
 #ifdef ESCAT_STAMPS
             if (t == 1) STAMP(part, 5);
+            if (t == 5) { STAMPW(part, 11, 0); STAMPW(part, 15, NT - 64); }
 #endif
             if (!staged) {                        // after the first step: start the DMA of the next part's input
                 const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);

@@ -75,6 +75,8 @@ _SELL_DMAX = {1: (8, 16, 24, 32), 9: (8, 12, 16, 20, 22)}     # register capacit
 # rows longer than the capacity stream their tail from L2 every step (slow for their whole workgroup), but the largest
 # BSR-3 capacity leaves the kernel short of registers: accept a capacity that leaves at most this fraction of rows a tail
 _SELL_TAIL_ROWS = 5e-5
+# order of a 3x3 block's entries in the fused-chain pack: b00 b10 b01 b11 | b02 b12 b20 b21 | b22 (include/escat.h)
+_BSR3_PIECE_ORDER = (0, 3, 1, 4, 2, 5, 6, 7, 8)
 
 
 def _cumsum0(t):
@@ -166,8 +168,8 @@ class Sell:
         if V == 9:
             val = torch.zeros((total_d + 1) * 576, dtype=torch.float32, device=dev)     # + one padding slot (empty slices read it)
             src = form.val.reshape(nnz, 9)[e_k]
-            for q in range(9):
-                dst = drow * 576 + (q // 4) * 256 + (lane * 4 + q % 4 if q < 8 else lane)
+            for sp, q in enumerate(_BSR3_PIECE_ORDER):      # stored position sp holds block entry q (row-major)
+                dst = drow * 576 + (sp // 4) * 256 + (lane * 4 + sp % 4 if sp < 8 else lane)
                 val[dst] = src[:, q]
         else:
             val = torch.zeros((total_d + 1) * 64, dtype=torch.float32, device=dev)

@@ -67,7 +67,7 @@ typedef struct { int32_t step, slot, sign, chan; } escat_event;
  * entries of each row, slot-major:
  *   CSR   val[(doff_s + d)*64 + lane]
  *   BSR-3 val[(doff_s + d)*576 + {lane*4+0..3 | 256+lane*4+0..3 | 512+lane}]
- *         = block floats 0-3 | 4-7 | 8
+ *         = block entries b00 b10 b01 b11 | b02 b12 b20 b21 | b22  (bij = row i, column j; pairs for packed fp32 FMAs)
  *   lc[(poff_s + d/2)*64 + lane] = LDS row of slot d | LDS row of slot d+1 << 16, where the LDS row of an entry
  *         with local column a (= column - first row of the part) is a (copy A of the vector) or R + copyB(a)
  *         (copy B; R = rows of the part + 1 rounded up to 16, copyB rotates bits 0-3 of a to the top of its

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from the two --pmc passes of tools/prof_bench.sh.
+usage: python tools/pmc_to_traffic.py gpurun_out/prof_<tag> [graphs nodes k J]"""
+import csv, glob, json, os, sys, collections
+root = sys.argv[1]
+cfg = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else [4096, 500, 10, 4]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    for f in glob.glob(os.path.join(root, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            n = r["Kernel_Name"]
+            if "k_chain" in n and r["Counter_Name"] == ctr:
+                acc[n.split("(")[0].replace("void ", "").strip()][ctr].append(float(r["Counter_Value"]))
+out = {"config": dict(zip(("graphs", "nodes", "k", "J"), cfg)),
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 3 --warmup 1` "
+                 "(tools/prof_bench.sh, tools/pmc_to_traffic.py); unit KB per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                 "(gfx950 tallies 128-B requests of 16 B/lane streaming reads at 64 B); 8/9 of the operator bytes are read with "
+                 "16 B/lane loads, the rest with 4 B/lane loads (uncalibrated, also doubled: upper bound)",
+       "kernels": {}}
+for k, v in acc.items():
+    f, w = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
+    if not f or not w:
+        continue
+    fm, wm = sum(f) / len(f), sum(w) / len(w)
+    out["kernels"][k] = {"FETCH_SIZE_KB_mean": fm, "WRITE_SIZE_KB_mean": wm, "dispatches": len(f),
+                         "hbm_bytes_per_launch_corrected": int((2 * fm + wm) * 1024)}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))

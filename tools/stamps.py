@@ -34,14 +34,14 @@ for J in (0, 4):
         return None
     for _ in range(2):
         f = run(); f and f()
-    st = torch.zeros(G * 8, dtype=torch.int64, device=dev)
+    st = torch.zeros(G * 16, dtype=torch.int64, device=dev)
     f = run()
     raw.escat_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))
     if f: f()
     else: get_Batch_Wjxs(x, op, J=J)
     torch.cuda.synchronize()
     raw.escat_debug_set_stamps(ctypes.c_void_p(0))
-    s = st.cpu().numpy().reshape(G, 8).astype(np.int64)
+    s = st.cpu().numpy().reshape(G, 16).astype(np.int64)
     names = ["operator loads issued", "previous epilogue issued", "input wait + barrier", "prologue", "step 1 (waits for the operator)",
              "steps 2..T", "post-step wait"]
     print(f"== {which} {'bwd' if bwd else 'fwd'} J={J}: span {us(s[:, 6].max() - s[:, 0].min()):.1f} us")
@@ -50,5 +50,12 @@ for J in (0, 4):
         ok = (a > 0) & (bb > 0)
         d = us(bb[ok] - a[ok])
         print(f"   {nm:34s} +{d.mean():7.2f} us (p10 {np.percentile(d, 10):6.2f}, p90 {np.percentile(d, 90):6.2f})")
+    if J > 0:
+        for nm, o in (("wave 0 (longest slice)", 8), ("last wave (shortest slice)", 12)):
+            ok = (s[:, o] > 0) & (s[:, o + 3] > 0)
+            g, e, bq = us(s[ok, o + 1] - s[ok, o]), us(s[ok, o + 2] - s[ok, o + 1]), us(s[ok, o + 3] - s[ok, o + 2])
+            print(f"   step 5, {nm:28s}: gather {g.mean():5.2f}  events+store {e.mean():5.2f}  barrier wait {bq.mean():5.2f} us")
+        ok = (s[:, 8] > 0) & (s[:, 12] > 0)
+        print(f"   step 5 start skew last-first wave: {us(s[ok, 12] - s[ok, 8]).mean():5.2f} us")
     ok = s[:, 7] > 0
     print(f"   part total (0 -> 7)                {us(s[ok, 7] - s[ok, 0]).mean():7.2f} us")
