@@ -28,7 +28,8 @@ class EscatSell(ctypes.Structure):
     _fields_ = [("val", ctypes.c_void_p), ("lc", ctypes.c_void_p), ("lane_meta", ctypes.c_void_p),
                 ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("slices_per_part", ctypes.c_int32),
                 ("reserved", ctypes.c_int32),
-                ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p)]
+                ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p),
+                ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/escat.h declares

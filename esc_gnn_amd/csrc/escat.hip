@@ -539,7 +539,8 @@ __device__ __forceinline__ float apply_events(const EvTable &tab, int q0, int q1
 //       a part, with no dependent second hop.
 struct SellDev {
     const float *val; const unsigned *lc; const int *lane_meta;
-    int dmax, nsl;
+    const int *part_list, *part_row0;             // optional: the launch covers parts part_list[i], whose rows of the
+    int dmax, nsl;                                // dense operands start at part_row0[i] (a batch drawn from a store)
 };
 
 #define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
@@ -808,8 +809,10 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int in_w = BWD ? C * F : C;                            // input floats per row
 
-    int part = blockIdx.x;
-    if (part >= n_parts) return;
+    int li = blockIdx.x;                          // index into the launch's list of parts
+    if (li >= n_parts) return;
+    int part = sd.part_list ? sd.part_list[li] : li;            // part of the packed operator
+    int row0 = sd.part_row0 ? sd.part_row0[li] : -1;            // first row in IN / RES (-1: the operator's own)
     Op op;
     // first part: nothing to hide behind
     int rt, te0, sw;
@@ -817,20 +820,28 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         const int *lm = sd.lane_meta + ((int64_t)(part * sd.nsl + wave) * 64 + lane) * 3;
         rt = lm[0]; te0 = lm[1]; sw = lm[2];
         const int gs0 = __builtin_amdgcn_readlane(sw, 3), rows0 = __builtin_amdgcn_readlane(sw, 4);
-        dma_in<NT>(BWD ? slab : inb, IN + (int64_t)gs0 * in_w, rows0 * in_w);
+        if (row0 < 0) row0 = gs0;
+        dma_in<NT>(BWD ? slab : inb, IN + (int64_t)row0 * in_w, rows0 * in_w);
     }
-    int prev_gs = 0, prev_rows = -1;              // part whose result is still in LDS (epilogue pending)
+    int prev_row0 = 0, prev_rows = -1;            // part whose result is still in LDS (epilogue pending)
     for (;;) {
+        // which part comes next (read now, needed after the prologue)
+        const int liN = li + gridDim.x;
+        const bool has_next = liN < n_parts;      // uniform
+        int partN = liN, row0N = -1;
+        if (has_next && sd.part_list) partN = sd.part_list[liN];
+        if (has_next && sd.part_row0) row0N = sd.part_row0[liN];
+
         const int doff = __builtin_amdgcn_readlane(sw, 0), poff = __builtin_amdgcn_readlane(sw, 1);
         const int w = __builtin_amdgcn_readlane(sw, 2);
         const int gs = __builtin_amdgcn_readlane(sw, 3), rows = __builtin_amdgcn_readlane(sw, 4);
         // the operator registers are dead here: refill them ...
-        STAMP(part, 0);
+        STAMP(li, 0);
         op.load(sd, doff, poff, w, lane);
-        STAMP(part, 1);
+        STAMP(li, 1);
         // ... and store the previous part's result underneath the stream
-        if (prev_rows >= 0) chain_epilogue<BWD, NT>(xa, slab, RES, prev_gs, prev_rows, C, CP, F);
-        STAMP(part, 2);
+        if (prev_rows >= 0) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+        STAMP(li, 2);
 
         const int R = sell_padR(rows);
         const int r = (rt & 0x3ff) == 0x3ff ? -1 : (rt & 0x3ff);
@@ -841,15 +852,13 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         // returned in order, for the operator issued after it; otherwise it landed many steps ago)
         if (prev_rows < 0 || (BWD && !early)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                          // every wave's copy has landed; the epilogue's LDS reads are done
-        STAMP(part, 3);
+        STAMP(li, 3);
         int p = chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab);
-        STAMP(part, 4);
+        STAMP(li, 4);
 
-        const int next = part + gridDim.x;
-        const bool has_next = next < n_parts;     // uniform
         int rtN = 0, te0N = 0, swN = 0;
         if (has_next) {                           // metadata of the next part: lands during the first step
-            const int *lm = sd.lane_meta + ((int64_t)(next * sd.nsl + wave) * 64 + lane) * 3;
+            const int *lm = sd.lane_meta + ((int64_t)(partN * sd.nsl + wave) * 64 + lane) * 3;
             rtN = lm[0]; te0N = lm[1]; swN = lm[2];
         }
         bool staged = !(has_next && (!BWD || early));   // "nothing to stage early"
@@ -860,11 +869,11 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = 0.f;
 #ifdef ESCAT_STAMPS
-            if (t == 5) { STAMPW(part, 8, 0); STAMPW(part, 12, NT - 64); }
+            if (t == 5) { STAMPW(li, 8, 0); STAMPW(li, 12, NT - 64); }
 #endif
             op.gather(xa, w, acc);
 #ifdef ESCAT_STAMPS
-            if (t == 5) { STAMPW(part, 9, 0); STAMPW(part, 13, NT - 64); }
+            if (t == 5) { STAMPW(li, 9, 0); STAMPW(li, 13, NT - 64); }
 #endif
             if (own) {
                 if (tn) Op::tail(val, col, te0, tn, gs, xa, acc);
@@ -876,34 +885,35 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
             }
 #ifdef ESCAT_STAMPS
-            if (t == 5) { STAMPW(part, 10, 0); STAMPW(part, 14, NT - 64); }
+            if (t == 5) { STAMPW(li, 10, 0); STAMPW(li, 14, NT - 64); }
 #endif
             __syncthreads();
             float *tmp = xa; xa = xb; xb = tmp;
 #ifdef ESCAT_STAMPS
-            if (t == 1) STAMP(part, 5);
-            if (t == 5) { STAMPW(part, 11, 0); STAMPW(part, 15, NT - 64); }
+            if (t == 1) STAMP(li, 5);
+            if (t == 5) { STAMPW(li, 11, 0); STAMPW(li, 15, NT - 64); }
 #endif
             if (!staged) {                        // after the first step: start the DMA of the next part's input
                 const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
-                dma_in<NT>(inb, IN + (int64_t)gsN * in_w, rowsN * in_w);
+                dma_in<NT>(inb, IN + (int64_t)(row0N < 0 ? gsN : row0N) * in_w, rowsN * in_w);
                 staged = true;
             }
         }
-        prev_gs = gs; prev_rows = rows;
-        STAMP(part, 6);
+        prev_row0 = row0; prev_rows = rows;
+        STAMP(li, 6);
         if (!has_next) break;
         {
             const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
+            if (row0N < 0) row0N = gsN;
             // fwd / early bwd with T == 0 never reached the in-loop DMA; the single-slab bwd copies now (its slab is dead)
-            if (!staged || (BWD && !early)) dma_in<NT>(inb, IN + (int64_t)gsN * in_w, rowsN * in_w);
+            if (!staged || (BWD && !early)) dma_in<NT>(inb, IN + (int64_t)row0N * in_w, rowsN * in_w);
             if (!BWD || early) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged long ago: costs nothing
         }
-        STAMP(part, 7);
-        part = next; rt = rtN; te0 = te0N; sw = swN;
+        STAMP(li, 7);
+        li = liN; part = partN; row0 = row0N; rt = rtN; te0 = te0N; sw = swN;
         if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
     }
-    chain_epilogue<BWD, NT>(xa, slab, RES, prev_gs, prev_rows, C, CP, F);
+    chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
 }
 
 // ------------------------------------------------------------------ pack-time slot planning
@@ -1157,13 +1167,18 @@ static int chain_path_override()
     return 0;
 }
 
+#define LIST_NEEDS_REG "escat_sell.part_list needs the register-resident path (a packed operator whose parts have <= 512 rows and fit LDS)"
+
 static int sell_to_dev(const escat_sell *sell, SellDev *sd)
 {
     if (!sell->val || !sell->lc || !sell->lane_meta) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
     if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
     if (sell->slices_per_part != 4 && sell->slices_per_part != 8)
         return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d: must be 4 (parts <= 256 rows) or 8", sell->slices_per_part);
+    if ((sell->part_list != nullptr) != (sell->part_row0 != nullptr) || (sell->part_list && sell->n_list < 0))
+        return fail(ESCAT_EINVAL, "escat_sell.part_list and part_row0 go together (n_list >= 0)");
     sd->val = sell->val; sd->lc = sell->lc; sd->lane_meta = sell->lane_meta; sd->dmax = sell->dmax; sd->nsl = sell->slices_per_part;
+    sd->part_list = sell->part_list; sd->part_row0 = sell->part_row0;
     return ESCAT_OK;
 }
 
@@ -1295,14 +1310,17 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
             if (max_part_rows <= 512 && sell && force != 2 && lds_s <= LDS_BUDGET) {
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
-                rc = launch_csr_sell<BWD>(C, max_part_rows, col, val, n_parts, sd, IN, RES, T, tab, F, st);
-            } else
+                rc = launch_csr_sell<BWD>(C, max_part_rows, col, val, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
+            } else if (sell && sell->part_list)
+                return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
+            else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_csr");
             return ESCAT_OK;
         }
     }
+    if (sell && sell->part_list) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
     // multi-launch path
     const size_t need = (size_t)2 * n * C * sizeof(float);
     if (T > 0 && (!workspace || workspace_bytes < need))
@@ -1382,11 +1400,12 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
         if (lds <= LDS_BUDGET && lds_s <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
-            rc = launch_bsr3_sell<BWD>(max_part_rows, col, blk, n_parts, sd, IN, RES, T, tab, F, st);
+            rc = launch_bsr3_sell<BWD>(max_part_rows, col, blk, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_bsr3_sell");
             return ESCAT_OK;
         }
+        if (sell && sell->part_list) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
         if (lds <= LDS_BUDGET) {
 #define GO(gg)                                                                                          \
             rc = set_lds(k_chain_bsr3<gg, BWD>, lds); if (rc) return rc;                                \
@@ -1397,6 +1416,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
             return ESCAT_OK;
         }
     }
+    if (sell && sell->part_list) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
     if (sell && sell->col32 && T > 0) {
         // packed multi-launch path: float4-per-node intermediate vectors
         if (!sell->val || !sell->perm || !sell->slice_doff) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");

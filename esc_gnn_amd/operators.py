@@ -405,8 +405,9 @@ class ScatterOperator:
             rp = c.rowptr.long()
             rows = torch.repeat_interleave(torch.arange(c.n, device=self.device), rp[1:] - rp[:-1])
             order = torch.argsort(c.col.long() * c.n + rows)
+            # a block-diagonal operator and its transpose have the same diagonal blocks: same parts
             self._csr_t = _Csr(_rowptr(c.col.long()[order], c.n), rows[order].to(torch.int32),
-                               c.val[order].contiguous(), c.n)
+                               c.val[order].contiguous(), c.n, (c.part_ptr, c.n_parts, c.max_part_rows))
         return self._csr_t
 
     def bsr3_t(self) -> _Csr:
@@ -416,8 +417,71 @@ class ScatterOperator:
             rows = torch.repeat_interleave(torch.arange(b.n, device=self.device), rp[1:] - rp[:-1])
             order = torch.argsort(b.col.long() * b.n + rows)
             self._bsr_t = _Csr(_rowptr(b.col.long()[order], b.n), rows[order].to(torch.int32),
-                               b.val[order].transpose(1, 2).contiguous(), b.n)
+                               b.val[order].transpose(1, 2).contiguous(), b.n, (b.part_ptr, b.n_parts, b.max_part_rows))
         return self._bsr_t
+
+
+    # ---------------------------------------------------------------- batches drawn from a stored operator
+    def select(self, part_ids) -> "OperatorBatch":
+        """the mini-batch made of parts `part_ids` (any order, repeats allowed) of this operator -- a view: nothing is
+        copied, the kernels walk the listed parts of the packed operator in place (escat_sell.part_list)."""
+        return OperatorBatch(self, part_ids)
+
+    @staticmethod
+    def parts_from_graph_ptr(graph_ptr: torch.Tensor):
+        """explicit parts = graphs (pass as `parts=` to from_csr / from_bsr3 when building a store: one part per sample)"""
+        gp = graph_ptr.to(torch.int32).contiguous()
+        return gp, int(gp.numel()) - 1, int((gp[1:] - gp[:-1]).max()) if gp.numel() > 1 else 0
+
+
+class OperatorBatch:
+    """
+    A mini-batch drawn from a whole dataset's operator kept canonical + packed in HBM (build it once with one part
+    per sample: ScatterOperator.from_csr / from_bsr3(..., parts=ScatterOperator.parts_from_graph_ptr(graph_ptr))).
+    Rows of the dense operands follow the order of `part_ids`.  Accepted wherever a ScatterOperator is
+    (get_Batch_Wjxs, scatter); only the register-resident kernels support it.
+    """
+
+    def __init__(self, base: ScatterOperator, part_ids):
+        self.base = base
+        self.device = base.device
+        ids = torch.as_tensor(part_ids, device=base.device).to(torch.int64).flatten()
+        form = base.bsr3() if base.has_bsr3 else base.csr()
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= form.n_parts):
+            raise IndexError("escat: part id outside the stored operator")
+        self.part_ids = ids
+        self._ref_parts = form.n_parts
+        pp = form.part_ptr.long()
+        rows = (pp[1:] - pp[:-1])[ids]
+        self._unit = 3 if base.has_bsr3 else 1          # scalar rows per row of the reference form
+        self.n = int(rows.sum()) * self._unit
+        self._lists = {}
+
+    def lists_for(self, form):
+        """(part_list, part_row0) int32 device tensors in the row units of `form`."""
+        key = id(form)
+        if key not in self._lists:
+            if form.n_parts != self._ref_parts:
+                raise RuntimeError("escat: this form of the stored operator is partitioned differently; build the store "
+                                   "with explicit parts (one per sample)")
+            pp = form.part_ptr.long()
+            rows = (pp[1:] - pp[:-1])[self.part_ids]
+            row0 = _cumsum0(rows)[:-1]
+            self._lists[key] = (self.part_ids.to(torch.int32).contiguous(), row0.to(torch.int32).contiguous())
+        return self._lists[key]
+
+    def row_index(self) -> torch.Tensor:
+        """scalar rows of the stored operator, in batch order (to gather x / targets kept per dataset)."""
+        base = self.base
+        form = base.bsr3() if base.has_bsr3 else base.csr()
+        pp = form.part_ptr.long()
+        start, rows = pp[:-1][self.part_ids], (pp[1:] - pp[:-1])[self.part_ids]
+        off = _cumsum0(rows)
+        idx = torch.arange(int(off[-1]), device=self.device) - torch.repeat_interleave(off[:-1], rows) \
+            + torch.repeat_interleave(start, rows)
+        if self._unit == 3:
+            idx = (3 * idx[:, None] + torch.arange(3, device=self.device)[None, :]).reshape(-1)
+        return idx
 
 
 def _validate(rowptr, col, n):
@@ -430,9 +494,9 @@ def _validate(rowptr, col, n):
         raise ValueError("column index out of range")
 
 
-def as_operator(P_sparse) -> ScatterOperator:
+def as_operator(P_sparse):
     """torch sparse tensor (or a ScatterOperator) -> ScatterOperator, cached on the tensor object."""
-    if isinstance(P_sparse, ScatterOperator):
+    if isinstance(P_sparse, (ScatterOperator, OperatorBatch)):
         return P_sparse
     op = getattr(P_sparse, "_escat_operator", None)
     if op is None:

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .operators import ScatterOperator, as_operator
+from .operators import ScatterOperator, OperatorBatch, as_operator
 from .scales import ChainPlan, plan_chain
 
 LDS_BUDGET = 160 * 1024
@@ -47,11 +47,15 @@ def chain_lds_bytes(max_part_rows: int, C: int, F: int, bsr3: bool, backward: bo
     return (2 * 2 * sell_pad_rows(max_part_rows) * CP + slab + stage) * 4
 
 
-def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool) -> torch.Tensor:
-    """one call into the C ABI for <= MAX_C channels.  inp: fwd (n,C) / bwd (n,C,F); returns fwd (n,C,F) / bwd (n,C)."""
+def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool) -> torch.Tensor:
+    """one call into the C ABI for <= MAX_C channels.  inp: fwd (n,C) / bwd (n,C,F); returns fwd (n,C,F) / bwd (n,C).
+    op: a ScatterOperator, or an OperatorBatch (parts of a stored operator, walked in place)."""
     lib = _lib.load()
     dev = inp.device
-    n = op.n
+    view = op if isinstance(op, OperatorBatch) else None
+    if view is not None:
+        op = view.base
+    n = view.n if view is not None else op.n
     ev = _events_array(plan_events)
     use_bsr = C == 1 and op.has_bsr3
     form = (op.bsr3_t() if backward else op.bsr3()) if use_bsr else (op.csr_t() if backward else op.csr())
@@ -61,16 +65,24 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
     path = os.environ.get("ESCAT_CHAIN_PATH", "")
     fused = form.n_parts > 0 and lds <= LDS_BUDGET and not path.startswith("multi")
     ws = None
-    if not fused and T > 0:
+    if not fused and T > 0 and view is None:
         ws = torch.empty(lib.escat_chain_workspace_bytes(n, C) // 4, dtype=torch.float32, device=dev)
     ws_bytes = ws.numel() * 4 if ws is not None else 0
     sell = form.sell() if fused else None
     if sell is not None and (form.max_part_rows * rows_per * C > 0xffff or path == "stream"):
         sell = None
+    if view is not None and sell is None:
+        raise NotImplementedError("escat: an OperatorBatch needs the register-resident path (parts of <= 512 rows that fit LDS)")
+    if view is not None and n == 0:
+        return out
     sell_ref = ctypes.c_void_p(0)
     if sell is not None:
+        pl, pr, nl = 0, 0, 0
+        if view is not None:
+            plist, prow0 = view.lists_for(form)
+            pl, pr, nl = plist.data_ptr(), prow0.data_ptr(), int(plist.numel())
         sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(),
-                                     sell.dmax, sell.n_slices, sell.slices_per_part, 0, 0, 0, 0)
+                                     sell.dmax, sell.n_slices, sell.slices_per_part, 0, 0, 0, 0, pl, pr, nl)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
@@ -78,7 +90,7 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
         # random node order where the x gather dominates), so the default multi-launch path stays unpacked.
         sg = form.sell_global()
         sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, 0, 0, sg.n_slices, 0, 0,
-                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr())
+                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -96,7 +108,7 @@ def _chain_launch(op: ScatterOperator, plan_events, T, F, inp: torch.Tensor, C: 
     return out
 
 
-def _run_chain(op: ScatterOperator, plan: ChainPlan, inp: torch.Tensor, backward: bool) -> torch.Tensor:
+def _run_chain(op, plan: ChainPlan, inp: torch.Tensor, backward: bool) -> torch.Tensor:
     C = inp.shape[1]
     if C <= MAX_C:
         return _chain_launch(op, plan.events, plan.T, plan.F, inp.contiguous(), C, backward)

@@ -97,6 +97,14 @@ typedef struct {
     const int32_t  *col32;
     const int32_t  *perm;
     const int32_t  *slice_doff;
+    /* optional batch view (register-resident path only): the launch covers the n_list parts part_list[i] of the packed
+     * operator, in that order; the rows of part part_list[i] in the dense operands (X / OUT / G / dX) start at
+     * part_row0[i] (the dense operands then have sum-of-listed-rows rows, not the operator's n).  This is how a
+     * shuffled mini-batch is drawn from a whole dataset's operators kept packed in HBM, with no copy and no re-ingest.
+     * NULL / NULL / 0: all parts, rows as in the operator. */
+    const int32_t  *part_list;
+    const int32_t  *part_row0;
+    int32_t         n_list;
 } escat_sell;
 
 /* Pack-time planning for escat_sell: for every entry e among the first dmax of its row, the slot (column of its

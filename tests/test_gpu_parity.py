@@ -343,6 +343,48 @@ def test_persistent_pipeline_many_ragged_parts():
         _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=2e-5)
 
 
+def test_operator_batch_views_of_a_stored_operator():
+    """mini-batches drawn by part ids from a stored (canonical + packed) operator, with no copy: forward and backward of
+    a shuffled subset equal the corresponding rows of the full run bit for bit (graphs are independent)."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic
+    dev = _dev()
+    bs = [synthetic.ellipsoid_batch(200, 500, 8, seed=11), synthetic.ellipsoid_batch(250, 210, 8, seed=12),
+          synthetic.ellipsoid_batch(200, 380, 8, seed=13)]
+    b = _concat_batches(bs)
+    gp = np.concatenate([[0], np.cumsum([n for bb, n in zip(bs, (500, 210, 380)) for _ in range(bb["N"] // n)])])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    parts = ScatterOperator.parts_from_graph_ptr(t(gp))
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"], parts=parts)
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"], parts=parts)
+    assert opP.csr().n_parts == 650 and opQ.bsr3().n_parts == 650
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b["N"], 3, generator=g).to(dev)
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1).to(dev)
+    ids = torch.randperm(650, generator=g)[:601]
+    for J in (3, 0):
+        Wf = get_Batch_Wjxs(x, opP, J=J); Wqf = get_Batch_Wjxs(xv, opQ, J=J)
+        vP, vQ = opP.select(ids), opQ.select(ids)
+        rP, rQ = vP.row_index(), vQ.row_index()
+        assert vP.n == rP.numel() and vQ.n == rQ.numel() == 3 * rP.numel()
+        xs = x[rP].clone().requires_grad_(True); xq = xv[rQ].clone().requires_grad_(True)
+        W = get_Batch_Wjxs(xs, vP, J=J); Wq = get_Batch_Wjxs(xq, vQ, J=J)
+        assert torch.equal(W, Wf[rP]) and torch.equal(Wq, Wqf[rQ])
+        # backward: upstream gradient of the batch scattered into the store's rows
+        G = torch.randn(W.shape, generator=g).to(dev); Gq = torch.randn(Wq.shape, generator=g).to(dev)
+        W.backward(G); Wq.backward(Gq)
+        xf = x.clone().requires_grad_(True); xqf = xv.clone().requires_grad_(True)
+        Gf = torch.zeros_like(Wf); Gf[rP] = G
+        Gqf = torch.zeros_like(Wqf); Gqf[rQ] = Gq
+        get_Batch_Wjxs(xf, opP, J=J).backward(Gf); get_Batch_Wjxs(xqf, opQ, J=J).backward(Gqf)
+        assert torch.equal(xs.grad, xf.grad[rP]) and torch.equal(xq.grad, xqf.grad[rQ])
+    # repeats are allowed; an empty batch is a no-op
+    rep = opP.select(torch.tensor([5, 5, 7]))
+    Wr = get_Batch_Wjxs(x[rep.row_index()], rep, J=2)
+    n5 = int(gp[6] - gp[5])
+    assert torch.equal(Wr[:n5], Wr[n5:2 * n5])
+    assert get_Batch_Wjxs(x[:0], opP.select(torch.zeros(0, dtype=torch.long)), J=2).shape[0] == 0
+
+
 def test_register_path_long_rows_and_small_parts():
     """rows longer than the register capacity (DMAX) take the streamed tail; parts of many tiny graphs."""
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain

@@ -188,3 +188,27 @@ def test_product_path_refuses_cpu(sg):
         get_Batch_Wjxs(torch.from_numpy(sg["x_C3"]), P, scales_type="nope")
     with pytest.raises(NotImplementedError):
         get_Batch_Wjxs(torch.from_numpy(sg["x_C3"]), P, J=2, rescale_filtrations=True)
+
+
+def test_operator_batch_view_index_logic():
+    """OperatorBatch (host logic, CPU tensors): part lists, first rows and the row index of a drawn batch."""
+    import torch
+    from esc_gnn_amd import ScatterOperator
+    # three graphs of 2, 3, 1 nodes: block-diagonal identity-like CSR
+    n = 6
+    rowptr = torch.arange(n + 1, dtype=torch.int32); col = torch.arange(n, dtype=torch.int32); val = torch.ones(n)
+    gp = torch.tensor([0, 2, 5, 6])
+    op = ScatterOperator.from_csr(rowptr, col, val, n, parts=ScatterOperator.parts_from_graph_ptr(gp))
+    v = op.select([2, 0, 0, 1])
+    assert v.n == 1 + 2 + 2 + 3
+    assert v.row_index().tolist() == [5, 0, 1, 0, 1, 2, 3, 4]
+    pl, r0 = v.lists_for(op.csr())
+    assert pl.tolist() == [2, 0, 0, 1] and r0.tolist() == [0, 1, 3, 5] and pl.dtype == torch.int32
+    # the transposed form keeps the forward form's parts
+    assert op.csr_t().n_parts == 3 and v.lists_for(op.csr_t())[1].tolist() == [0, 1, 3, 5]
+    import pytest
+    with pytest.raises(IndexError):
+        op.select([3])
+    blk = torch.eye(3).repeat(n, 1, 1)
+    q = ScatterOperator.from_bsr3(rowptr, col, blk, n, parts=ScatterOperator.parts_from_graph_ptr(gp)).select([1])
+    assert q.n == 9 and q.row_index().tolist() == list(range(6, 15))
