@@ -305,13 +305,21 @@ class ScatterOperator:
         self._bsr: Optional[_Csr] = None
         self._bsr_t: Optional[_Csr] = None
         self._coo = None                # (rows, cols, vals) coalesced, int64: source for lazy forms
+        self._graph_ptr = None          # optional explicit parts (scalar rows), one per sample of a store
         self.bsr_fill = 0.0
+
+    def _parts_for(self, unit: int):
+        """explicit parts for a form whose rows are `unit` scalar rows each (None: find the closed row ranges)"""
+        if self._graph_ptr is None:
+            return None
+        return ScatterOperator.parts_from_graph_ptr(self._graph_ptr // unit)
 
     # ---------------------------------------------------------------- constructors
     @staticmethod
-    def from_torch(A: torch.Tensor, allow_cpu: bool = False) -> "ScatterOperator":
+    def from_torch(A: torch.Tensor, allow_cpu: bool = False, graph_ptr=None) -> "ScatterOperator":
         # allow_cpu exists for host-logic tests of the canonical index structure only;
         # get_Batch_Wjxs refuses CPU tensors.
+        # graph_ptr (scalar rows, [B+1]): the samples of a block-diagonal store -> one part each (see select()).
         if not A.is_cuda and not allow_cpu:
             raise RuntimeError("escat: the operator must live on a GPU (no CPU fallback in the product path)")
         if A.dim() != 2 or A.shape[0] != A.shape[1]:
@@ -332,6 +340,10 @@ class ScatterOperator:
             raise TypeError(f"escat: unsupported operator layout {A.layout}")
         op = ScatterOperator(n, A.device)
         op._coo = (rows.long(), col.long(), val.to(torch.float32))
+        if graph_ptr is not None:
+            op._graph_ptr = torch.as_tensor(graph_ptr, device=A.device).to(torch.int64)
+            if int(op._graph_ptr[-1]) != n or int(op._graph_ptr[0]) != 0:
+                raise ValueError("escat: graph_ptr must run from 0 to the operator size")
         if n % 3 == 0 and op._coo[0].numel() > 0:
             op._try_bsr3()
         return op
@@ -370,7 +382,10 @@ class ScatterOperator:
         blk = torch.zeros(nnzb * 9, dtype=torch.float32, device=vals.device)
         blk.index_put_((inv * 9 + (rows % 3) * 3 + (cols % 3),), vals)
         brow = ub // nb
-        self._bsr = _Csr(_rowptr(brow, nb), (ub % nb).to(torch.int32), blk.view(nnzb, 3, 3), nb)
+        parts = None
+        if self._graph_ptr is not None and bool((self._graph_ptr % 3 == 0).all()):
+            parts = self._parts_for(3)
+        self._bsr = _Csr(_rowptr(brow, nb), (ub % nb).to(torch.int32), blk.view(nnzb, 3, 3), nb, parts)
 
     @property
     def has_bsr3(self) -> bool:
@@ -380,7 +395,7 @@ class ScatterOperator:
         if self._csr is None:
             if self._coo is not None:
                 rows, cols, vals = self._coo
-                self._csr = _Csr(_rowptr(rows, self.n), cols.to(torch.int32), vals.contiguous(), self.n)
+                self._csr = _Csr(_rowptr(rows, self.n), cols.to(torch.int32), vals.contiguous(), self.n, self._parts_for(1))
             else:   # expand BSR-3 to scalar CSR
                 b = self._bsr
                 rp = b.rowptr.long()

@@ -1,0 +1,51 @@
+"""
+Operator store: a whole dataset's P and Q kept canonical + packed in HBM, one part per sample, so that every epoch's
+shuffled mini-batches are views (ScatterOperator.select) instead of a per-step COO upload + coalesce
+(the reference re-reads /{P,Q}/{idx} per sample and collates int64 COO every step:
+models/escgnn_data_classes.py:113-143, 20-27).
+"""
+from typing import Dict, Optional, Sequence
+import numpy as np
+import torch
+
+from .operators import ScatterOperator
+
+
+def load_operator_store(path: str, device, indices: Optional[Sequence[int]] = None, pack: bool = True) -> Dict:
+    """
+    Reads the reference's HDF5 operator layout (/{P,Q}/{idx}/{indices,values,size},
+    scripts/python/generate_ellipsoid_dataset.py:1185-1206) for the samples `indices` (default: all, in numeric order)
+    and returns {"P": ScatterOperator, "Q": ScatterOperator, "graph_ptr": int64 (B+1,) node offsets, "ids": list}.
+    Values stored as fp16 are widened to fp32 as the reference loader does (escgnn_data_classes.py:137-142).
+    The operators carry one part per sample; with pack=True the SELL packs of all four forms are built now.
+    """
+    from .hdf5_min import H5Reader
+    f = H5Reader(path)
+    try:
+        ids = sorted((int(k) for k in f["P"].keys())) if indices is None else [int(i) for i in indices]
+        out = {}
+        sizes = [int(f["P"][str(i)]["size"][...][0]) for i in ids]
+        gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        for key, unit in (("P", 1), ("Q", 3)):
+            rows, cols, vals = [], [], []
+            for g, i in enumerate(ids):
+                grp = f[key][str(i)]
+                idx = np.asarray(grp["indices"][...], dtype=np.int64)
+                if tuple(int(v) for v in grp["size"][...]) != (unit * sizes[g], unit * sizes[g]):
+                    raise ValueError(f"escat: {key}/{i} has size {grp['size'][...]} but P/{i} has {sizes[g]} nodes")
+                rows.append(idx[0] + unit * gp[g]); cols.append(idx[1] + unit * gp[g])
+                vals.append(np.asarray(grp["values"][...]).astype(np.float32))
+            n = unit * int(gp[-1])
+            A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([np.concatenate(rows), np.concatenate(cols)])).to(device),
+                                        torch.from_numpy(np.concatenate(vals)).to(device), (n, n))
+            op = ScatterOperator.from_torch(A, graph_ptr=torch.from_numpy(unit * gp))
+            if pack:
+                forms = (op.bsr3(), op.bsr3_t()) if (key == "Q" and op.has_bsr3) else (op.csr(), op.csr_t())
+                for form in forms:
+                    form.sell()
+            out[key] = op
+        out["graph_ptr"] = torch.from_numpy(gp).to(device)
+        out["ids"] = ids
+        return out
+    finally:
+        f.close()

@@ -204,6 +204,7 @@ def test_dataset_to_hdf5_and_back(tmp_path, bg):
     assert info["graphs"] == 5
     f = H5Reader(path)
     assert set(f.keys()) == {"P", "Q"} and set(f["P"].keys()) == {str(i) for i in range(5)}
+    per_graph_W = []
     for g, c in enumerate(clouds):
         ei = bo.knn_sym_edges(c, 5)
         one = process_pyg_data(_Data(pos=torch.from_numpy(c), edge_index=torch.from_numpy(ei), num_nodes=c.shape[0]),
@@ -223,4 +224,18 @@ def test_dataset_to_hdf5_and_back(tmp_path, bg):
         W = get_Batch_Wjxs(xv, Q, J=2)
         ref = __import__("oracle.chain_oracle", fromlist=["x"]).ref_get_Batch_Wjxs(xv.cpu(), Q.cpu(), J=2)
         assert (W.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+        per_graph_W.append(W)
     f.close()
+    # the same file as an operator store resident in HBM: shuffled mini-batches are views of it
+    from esc_gnn_amd.store import load_operator_store
+    store = load_operator_store(path, dev)
+    assert store["graph_ptr"].tolist() == gp.tolist() and store["Q"].bsr3().n_parts == 5 and store["P"].csr().n_parts == 5
+    order = [3, 0, 4, 1, 2]
+    vQ, vP = store["Q"].select(order), store["P"].select(order)
+    xv_all = pos.reshape(-1, 1)
+    Wv = get_Batch_Wjxs(xv_all[vQ.row_index()], vQ, J=2)
+    want = torch.cat([per_graph_W[g] for g in order])
+    assert (Wv - want).abs().max() <= 1e-6 * want.abs().max()
+    Wp = get_Batch_Wjxs(pos[vP.row_index()], vP, J=2)
+    Wp_full = get_Batch_Wjxs(pos, store["P"], J=2)
+    assert torch.equal(Wp, Wp_full[vP.row_index()])
