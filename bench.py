@@ -236,9 +236,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             sample = min(args.cpu_sample_graphs, args.graphs)
             gps1, s1 = cpu_baseline(b, sample, args.nodes, args.J, 1)
+            many = min(16, os.cpu_count() or 1)      # the box's CPU share for one GPU (os.cpu_count() is the whole host)
+            gpsn, sn = cpu_baseline(b, sample, args.nodes, args.J, many)
             out["cpu_baseline"] = {"value": gps1, "unit": "graphs/s", "cores": 1, "kind": "port",
                                    "sample": f"first {sample} graphs of the same batch, fwd+bwd of both tracks, "
                                              f"torch.sparse.mm COO restatement of the reference, {s1:.1f} s",
+                                   "value_torch_threads_16": gpsn, "threads_16_seconds": sn,
+                                   "note": "torch's CPU COO product is serial per nonzero: more threads do not help (SURVEY 6)",
                                    "host_cpus": os.cpu_count()}
         print(json.dumps(out))
     if world > 1:
