@@ -44,7 +44,7 @@ SIGNATURES = {
     "escat_chain_bsr3_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_scatter_orders_f32": (ci, [vp, vp, i64, ci, ci, vp, vp]),
-    "escat_scatter_orders_bwd_f32": (ci, [vp, vp, i64, ci, ci, vp, vp, vp]),
+    "escat_scatter_orders_bwd_f32": (ci, [vp, i64, vp, i64, ci, ci, vp, vp, vp]),
     "escat_sell_plan_slots": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]),
     "escat_build_workspace_bytes": (sz, [i64, ci, ci]),
     "escat_build_knn_P": (ci, [vp, vp, ci, i64, ci, ci, vp, vp, vp, i64, vp, vp, sz, vp]),

@@ -1001,13 +1001,13 @@ k_scatter_orders(const float *__restrict__ x0, const float *__restrict__ W1, int
 }
 
 __global__ void __launch_bounds__(256)
-k_scatter_orders_bwd(const float *__restrict__ W1, const float *__restrict__ dW, int64_t rows, int F, int Wtot,
+k_scatter_orders_bwd(const float *__restrict__ W1, int64_t ldw1, const float *__restrict__ dW, int64_t rows, int F, int Wtot,
                      int second, float *__restrict__ dx0, float *__restrict__ dW1)
 {
     const int64_t total = rows * F;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int64_t r = idx / F; const int f = (int)(idx % F);
-        const float *d = dW + r * Wtot; const float *w1 = W1 + r * F;
+        const float *d = dW + r * Wtot; const float *w1 = W1 + r * ldw1;
         if (f == 0) dx0[r] = d[0];
         float g = d[1 + f];
         if (second) {
@@ -1019,6 +1019,84 @@ k_scatter_orders_bwd(const float *__restrict__ W1, const float *__restrict__ dW,
                 }
         }
         dW1[idx] = g;
+    }
+}
+
+// Tiled forms for the bank sizes that occur (F <= 9): one thread per row builds / consumes its Wtot values in registers,
+// a wave-private LDS tile turns the (rows, Wtot) side into whole-line 16-byte accesses.  The element-wise kernels above
+// re-derive the pair index per element and move 4 bytes per lane: 1.8 TB/s; these run at the copy rate.
+template <int F, bool SECOND>
+__global__ void __launch_bounds__(256)
+k_orders_fwd_t(const float *__restrict__ x0, const float *__restrict__ W1, int64_t rows, float *__restrict__ W)
+{
+    constexpr int WT = 1 + F + (SECOND ? F * (F - 1) / 2 : 0);
+    __shared__ __align__(16) float tile[4][64 * WT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *t = tile[wave];
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < rows; base += (int64_t)gridDim.x * 256) {
+        const int64_t wb = base + wave * 64, r = wb + lane;
+        if (r < rows) {
+            float w[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) w[f] = W1[r * F + f];
+            float *o = t + lane * WT;
+            o[0] = x0[r];
+#pragma unroll
+            for (int f = 0; f < F; ++f) o[1 + f] = w[f];
+            if (SECOND) {
+                int q = 1 + F;
+#pragma unroll
+                for (int i = 0; i < F; ++i)
+#pragma unroll
+                    for (int j = i + 1; j < F; ++j) o[q++] = w[i] * w[j];
+            }
+        }
+        __syncthreads();
+        const int64_t nv = rows - wb < 64 ? (rows - wb > 0 ? rows - wb : 0) : 64;      // valid rows of this wave's tile
+        const int n4 = (int)(nv * WT) / 4;
+        float4 *dst4 = reinterpret_cast<float4 *>(W + wb * WT);                        // wb*WT*4 B: a multiple of 16
+        const float4 *src4 = reinterpret_cast<const float4 *>(t);
+        for (int i = lane; i < n4; i += 64) dst4[i] = src4[i];
+        for (int i = n4 * 4 + lane; i < (int)(nv * WT); i += 64) W[wb * WT + i] = t[i];
+        __syncthreads();
+    }
+}
+
+template <int F, bool SECOND>
+__global__ void __launch_bounds__(256)
+k_orders_bwd_t(const float *__restrict__ W1, int64_t ldw1, const float *__restrict__ dW, int64_t rows,
+               float *__restrict__ dx0, float *__restrict__ dW1)
+{
+    constexpr int WT = 1 + F + (SECOND ? F * (F - 1) / 2 : 0);
+    __shared__ __align__(16) float tile[4][64 * WT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *t = tile[wave];
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < rows; base += (int64_t)gridDim.x * 256) {
+        const int64_t wb = base + wave * 64, r = wb + lane;
+        const int64_t nv = rows - wb < 64 ? (rows - wb > 0 ? rows - wb : 0) : 64;
+        const int n4 = (int)(nv * WT) / 4;
+        const float4 *src4 = reinterpret_cast<const float4 *>(dW + wb * WT);
+        float4 *dst4 = reinterpret_cast<float4 *>(t);
+        for (int i = lane; i < n4; i += 64) dst4[i] = src4[i];
+        for (int i = n4 * 4 + lane; i < (int)(nv * WT); i += 64) t[i] = dW[wb * WT + i];
+        __syncthreads();
+        if (r < rows) {
+            const float *d = t + lane * WT;
+            float g[F], w[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) { g[f] = d[1 + f]; w[f] = SECOND ? W1[r * ldw1 + f] : 0.f; }
+            if (SECOND) {
+                int q = 1 + F;
+#pragma unroll
+                for (int i = 0; i < F; ++i)
+#pragma unroll
+                    for (int j = i + 1; j < F; ++j) { const float dq = d[q++]; g[i] = fmaf(dq, w[j], g[i]); g[j] = fmaf(dq, w[i], g[j]); }
+            }
+            dx0[r] = d[0];
+#pragma unroll
+            for (int f = 0; f < F; ++f) dW1[r * F + f] = g[f];
+        }
+        __syncthreads();
     }
 }
 
@@ -1508,6 +1586,28 @@ extern "C" int escat_chain_bsr3_bwd_f32(const int32_t *rowptr_t, const int32_t *
                             workspace, workspace_bytes, stream);
 }
 
+template <bool SECOND>
+static bool launch_orders_fwd_t(int F, int grid, hipStream_t st, const float *x0, const float *W1, int64_t rows, float *W)
+{
+    switch (F) {
+#define CASE(f) case f: hipLaunchKernelGGL((k_orders_fwd_t<f, SECOND>), dim3(grid), dim3(256), 0, st, x0, W1, rows, W); return true;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+#undef CASE
+    }
+    return false;
+}
+template <bool SECOND>
+static bool launch_orders_bwd_t(int F, int grid, hipStream_t st, const float *W1, int64_t ldw1, const float *dW, int64_t rows,
+                                float *dx0, float *dW1)
+{
+    switch (F) {
+#define CASE(f) case f: hipLaunchKernelGGL((k_orders_bwd_t<f, SECOND>), dim3(grid), dim3(256), 0, st, W1, ldw1, dW, rows, dx0, dW1); return true;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+#undef CASE
+    }
+    return false;
+}
+
 extern "C" int escat_scatter_orders_f32(const float *x0, const float *W1, int64_t rows, int F, int second_order, float *W,
                                         void *stream)
 {
@@ -1515,20 +1615,29 @@ extern "C" int escat_scatter_orders_f32(const float *x0, const float *W1, int64_
     if (F < 1 || F > 64) return fail(ESCAT_ERANGE, "F=%d out of range [1,64]", F);
     if (rows <= 0) return rows == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative rows");
     const int Wtot = 1 + F + (second_order ? F * (F - 1) / 2 : 0);
-    hipLaunchKernelGGL(k_scatter_orders, dim3(grid_for(rows * Wtot, 256)), dim3(256), 0, S(stream), x0, W1, rows, F, Wtot, W);
+    const bool aligned = (((uintptr_t)W) & 15) == 0;
+    const int grid = grid_for(rows, 256);
+    if (!(aligned && (second_order ? launch_orders_fwd_t<true>(F, grid, S(stream), x0, W1, rows, W)
+                                   : launch_orders_fwd_t<false>(F, grid, S(stream), x0, W1, rows, W))))
+        hipLaunchKernelGGL(k_scatter_orders, dim3(grid_for(rows * Wtot, 256)), dim3(256), 0, S(stream), x0, W1, rows, F, Wtot, W);
     CHECK_LAUNCH("k_scatter_orders");
     return ESCAT_OK;
 }
 
-extern "C" int escat_scatter_orders_bwd_f32(const float *W1, const float *dW, int64_t rows, int F, int second_order,
+extern "C" int escat_scatter_orders_bwd_f32(const float *W1, int64_t ldw1, const float *dW, int64_t rows, int F, int second_order,
                                             float *dx0, float *dW1, void *stream)
 {
     if (!W1 || !dW || !dx0 || !dW1) return fail(ESCAT_EINVAL, "NULL pointer");
     if (F < 1 || F > 64) return fail(ESCAT_ERANGE, "F=%d out of range [1,64]", F);
+    if (ldw1 < F) return fail(ESCAT_EINVAL, "ldw1=%lld < F=%d", (long long)ldw1, F);
     if (rows <= 0) return rows == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative rows");
     const int Wtot = 1 + F + (second_order ? F * (F - 1) / 2 : 0);
-    hipLaunchKernelGGL(k_scatter_orders_bwd, dim3(grid_for(rows * F, 256)), dim3(256), 0, S(stream), W1, dW, rows, F, Wtot,
-                       second_order, dx0, dW1);
+    const bool aligned = (((uintptr_t)dW) & 15) == 0;
+    const int grid = grid_for(rows, 256);
+    if (!(aligned && (second_order ? launch_orders_bwd_t<true>(F, grid, S(stream), W1, ldw1, dW, rows, dx0, dW1)
+                                   : launch_orders_bwd_t<false>(F, grid, S(stream), W1, ldw1, dW, rows, dx0, dW1))))
+        hipLaunchKernelGGL(k_scatter_orders_bwd, dim3(grid_for(rows * F, 256)), dim3(256), 0, S(stream), W1, ldw1, dW, rows, F, Wtot,
+                           second_order, dx0, dW1);
     CHECK_LAUNCH("k_scatter_orders_bwd");
     return ESCAT_OK;
 }

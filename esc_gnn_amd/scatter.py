@@ -44,7 +44,7 @@ class _Orders(torch.autograd.Function):
         dx0 = torch.empty(W1c.shape[0], W1c.shape[1], dtype=torch.float32, device=W1c.device)
         dW1 = torch.empty_like(W1c)
         with torch.cuda.device(W1c.device):
-            rc = lib.escat_scatter_orders_bwd_f32(_ptr(W1c), _ptr(dWc), rows, F, int(ctx.second_order),
+            rc = lib.escat_scatter_orders_bwd_f32(_ptr(W1c), F, _ptr(dWc), rows, F, int(ctx.second_order),
                                                   _ptr(dx0), _ptr(dW1), _stream(W1c.device))
         _lib.check(rc, "escat_scatter_orders_bwd_f32")
         return dx0, dW1, None

@@ -192,8 +192,9 @@ int escat_chain_bsr3_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, cons
  * (:507-516)], Wtot = 1 + F + (second_order ? F(F-1)/2 : 0).  rows = n*C. */
 int escat_scatter_orders_f32(const float *x0, const float *W1, int64_t rows, int F,
                              int second_order, float *W, void *stream);
-/* its backward: dW (rows, Wtot) -> dx0 (rows,), dW1 (rows, F). */
-int escat_scatter_orders_bwd_f32(const float *W1, const float *dW, int64_t rows, int F,
+/* its backward: dW (rows, Wtot) -> dx0 (rows,), dW1 (rows, F).  W1 is read with row stride ldw1 floats (F for a
+ * dense bank; Wtot with W1 = W + 1 to read the bank out of the forward's own output). */
+int escat_scatter_orders_bwd_f32(const float *W1, int64_t ldw1, const float *dW, int64_t rows, int F,
                                  int second_order, float *dx0, float *dW1, void *stream);
 
 /* ---------------------------------------------------------------------------

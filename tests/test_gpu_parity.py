@@ -385,6 +385,32 @@ def test_operator_batch_views_of_a_stored_operator():
     assert get_Batch_Wjxs(x[:0], opP.select(torch.zeros(0, dtype=torch.long)), J=2).shape[0] == 0
 
 
+def test_orders_kernels_all_bank_sizes():
+    """escat_scatter_orders[_bwd]_f32: tiled kernels (F <= 9) and the element-wise fallback (F > 9, unaligned output)
+    against the reference formula (models/escgnn_modular.py:333-341) and its torch autograd, ragged row counts."""
+    from esc_gnn_amd.scatter import _Orders
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    for F in (1, 2, 5, 6, 9, 11):
+        for rows, C in ((1, 1), (63, 3), (64, 1), (1000, 3), (257, 5)):
+            for second in (True, False):
+                x0 = torch.randn(rows, C, generator=g).to(dev).requires_grad_(True)
+                W1 = torch.randn(rows, C, F, generator=g).to(dev).requires_grad_(True)
+                W = _Orders.apply(x0, W1, second)
+                parts = [x0.unsqueeze(-1), W1]
+                if second:
+                    i, j = torch.triu_indices(F, F, 1)
+                    if i.numel():
+                        parts.append(W1[..., i.to(dev)] * W1[..., j.to(dev)])
+                ref = torch.cat(parts, dim=-1)
+                assert W.shape == ref.shape and torch.equal(W, ref), (F, rows, C, second)
+                G = torch.randn(ref.shape, generator=g).to(dev)
+                gx, gw = torch.autograd.grad(W, (x0, W1), G)
+                rx, rw = torch.autograd.grad(ref, (x0, W1), G)
+                assert torch.equal(gx, rx)
+                assert (gw - rw).abs().max() <= 1e-5 * max(float(rw.abs().max()), 1.0), (F, rows, C, second)
+
+
 def test_register_path_long_rows_and_small_parts():
     """rows longer than the register capacity (DMAX) take the streamed tail; parts of many tiny graphs."""
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
