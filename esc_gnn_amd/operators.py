@@ -17,6 +17,7 @@ operator and cached on the tensor object); the products themselves never touch
 torch.
 """
 import os
+import os
 from typing import Optional
 import numpy as np
 import torch
@@ -68,6 +69,58 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
     out = np.unique(np.asarray(out, dtype=np.int64))
     max_rows = int(np.diff(out).max())
     return torch.from_numpy(out.astype(np.int32)).to(dev), len(out) - 1, max_rows
+
+
+REORDER_MIN_ROWS = 16384     # a connected block this large cannot live in LDS: its x gather goes to L2/HBM every step
+
+
+def locality_order(rowptr: torch.Tensor, col: torch.Tensor, n: int, max_components: int = 64) -> torch.Tensor:
+    """
+    Breadth-first (Cuthill-McKee style) ordering of the rows of a sparse structure: returns perm (new -> old) such that
+    rows that reference each other get nearby new indices.  Inside a BFS level rows are ordered by the rank of their
+    first-placed parent.  Torch index ops on the operator's device; O(levels) small launches, once per operator.
+    Point clouds arrive in arbitrary node order (the reference keeps the sampler's), which makes every step's gather of
+    x a random walk over HBM; after this ordering the rows a step touches together sit within a few BFS rings.
+    """
+    dev = rowptr.device
+    rp, cl = rowptr.long(), col.long()
+    deg = rp[1:] - rp[:-1]
+    rank = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    placed, comps = 0, 0
+    while placed < n:
+        unv = torch.nonzero(rank < 0).flatten()
+        if comps >= max_components:                       # many small pieces left: keep them in index order
+            rank[unv] = placed + torch.arange(unv.numel(), device=dev)
+            break
+        comps += 1
+        frontier = unv[:1]
+        rank[frontier] = placed
+        placed += 1
+        while frontier.numel() > 0:
+            cnt = deg[frontier]
+            tot = int(cnt.sum())
+            if tot == 0:
+                break
+            owner = torch.repeat_interleave(torch.arange(frontier.numel(), device=dev), cnt)
+            first = torch.cumsum(cnt, 0) - cnt
+            nb = cl[rp[frontier][owner] + (torch.arange(tot, device=dev) - first[owner])]
+            prank = rank[frontier][owner]
+            fresh = rank[nb] < 0
+            nb, prank = nb[fresh], prank[fresh]
+            if nb.numel() == 0:
+                break
+            key, order = torch.sort(nb * n + prank)       # by node, then by parent rank: first of a run = earliest parent
+            nb_s = nb[order]
+            head = torch.ones_like(nb_s, dtype=torch.bool)
+            head[1:] = nb_s[1:] != nb_s[:-1]
+            new_nodes, new_prank = nb_s[head], (key[head] - nb_s[head] * n)
+            o2 = torch.argsort(new_prank, stable=True)    # level order: by first parent, ties by node index
+            frontier = new_nodes[o2]
+            rank[frontier] = placed + torch.arange(frontier.numel(), device=dev)
+            placed += int(frontier.numel())
+    perm = torch.empty(n, dtype=torch.int64, device=dev)
+    perm[rank] = torch.arange(n, device=dev)
+    return perm
 
 
 SELL_MAX_PART_ROWS = 512
@@ -307,6 +360,8 @@ class ScatterOperator:
         self._coo = None                # (rows, cols, vals) coalesced, int64: source for lazy forms
         self._graph_ptr = None          # optional explicit parts (scalar rows), one per sample of a store
         self.bsr_fill = 0.0
+        self.row_perm = None            # set by _reorder_if_large: scalar rows, new -> old (x' = x[row_perm])
+        self.row_inv = None             # old -> new (y = y'[row_inv])
 
     def _parts_for(self, unit: int):
         """explicit parts for a form whose rows are `unit` scalar rows each (None: find the closed row ranges)"""
@@ -346,6 +401,7 @@ class ScatterOperator:
                 raise ValueError("escat: graph_ptr must run from 0 to the operator size")
         if n % 3 == 0 and op._coo[0].numel() > 0:
             op._try_bsr3()
+        op._reorder_if_large()
         return op
 
     @staticmethod
@@ -355,6 +411,8 @@ class ScatterOperator:
         if validate:
             _validate(rowptr, col, n)
         op._csr = _Csr(rowptr, col, val.to(torch.float32).contiguous(), n, parts)
+        if parts is None or parts[1] == 0:
+            op._reorder_if_large()
         return op
 
     @staticmethod
@@ -367,7 +425,42 @@ class ScatterOperator:
             raise ValueError("blk must be (nnzb, 3, 3)")
         op._bsr = _Csr(rowptr, col, blk.to(torch.float32).contiguous(), nb, parts)
         op.bsr_fill = 1.0
+        if parts is None or parts[1] == 0:
+            op._reorder_if_large()
         return op
+
+    # ---------------------------------------------------------------- locality reordering of huge connected blocks
+    def _reorder_if_large(self):
+        """If the operator has a connected block too large for LDS (one big point cloud: BASELINE cfg3), relabel its rows
+        in breadth-first order so that each step's gather of x stays inside L2.  Transparent: the chain permutes x on
+        the way in and the result on the way out (esc_gnn_amd.pyg_utilities._run_chain)."""
+        flag = os.environ.get("ESCAT_REORDER", "auto")
+        if flag == "0" or self._graph_ptr is not None:
+            return
+        form = self._bsr if self._bsr is not None else self.csr()
+        unit = 3 if form is self._bsr else 1
+        big = form.n_parts == 0 or form.max_part_rows > REORDER_MIN_ROWS
+        if form.n < 2 or form.nnz == 0 or not (big or flag == "1"):
+            return
+        n, dev = form.n, self.device
+        perm = locality_order(form.rowptr, form.col, n)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n, device=dev)
+        rp = form.rowptr.long()
+        rows_old = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+        r2, c2 = inv[rows_old], inv[form.col.long()]
+        order = torch.argsort(r2 * n + c2)
+        new = _Csr(_rowptr(r2[order], n), c2[order].to(torch.int32).contiguous(), form.val[order].contiguous(), n)
+        self._coo = None
+        self._csr = self._csr_t = self._bsr = self._bsr_t = None
+        if unit == 3:
+            self._bsr = new
+            a = torch.arange(3, device=dev)
+            self.row_perm = (3 * perm[:, None] + a[None, :]).reshape(-1)
+            self.row_inv = (3 * inv[:, None] + a[None, :]).reshape(-1)
+        else:
+            self._csr = new
+            self.row_perm, self.row_inv = perm, inv
 
     # ---------------------------------------------------------------- forms
     def _try_bsr3(self):

@@ -109,6 +109,13 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
 
 
 def _run_chain(op, plan: ChainPlan, inp: torch.Tensor, backward: bool) -> torch.Tensor:
+    base = op.base if isinstance(op, OperatorBatch) else op
+    if base.row_perm is not None:       # operator relabelled for locality (operators._reorder_if_large): x' = x[perm], y = y'[inv]
+        return _run_chain_cols(op, plan, inp[base.row_perm], backward)[base.row_inv]
+    return _run_chain_cols(op, plan, inp, backward)
+
+
+def _run_chain_cols(op, plan: ChainPlan, inp: torch.Tensor, backward: bool) -> torch.Tensor:
     C = inp.shape[1]
     if C <= MAX_C:
         return _chain_launch(op, plan.events, plan.T, plan.F, inp.contiguous(), C, backward)

@@ -411,6 +411,47 @@ def test_orders_kernels_all_bank_sizes():
                 assert (gw - rw).abs().max() <= 1e-5 * max(float(rw.abs().max()), 1.0), (F, rows, C, second)
 
 
+def test_locality_reordering_is_transparent(monkeypatch):
+    """a connected block too large for LDS is relabelled breadth-first at ingest (operators._reorder_if_large);
+    get_Batch_Wjxs permutes x in and the bank out, so results and gradients stay those of the original order."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    dev = _dev()
+    monkeypatch.setenv("ESCAT_REORDER", "1")                      # force it at a size the oracle finishes quickly
+    b = synthetic.single_cloud(3000, 8, workers=1)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    Pcoo = torch.sparse_coo_tensor(torch.stack([torch.repeat_interleave(torch.arange(b["N"]), torch.from_numpy(np.diff(b["rowptr"]).astype(np.int64))),
+                                                torch.from_numpy(b["col"]).long()]), torch.from_numpy(b["pval"]), (b["N"], b["N"])).to(dev)
+    opT = ScatterOperator.from_torch(Pcoo)
+    for op in (opQ, opP, opT):
+        assert op.row_perm is not None and sorted(op.row_perm.tolist()) == list(range(op.n))
+    # locality: mean |row - col| of the relabelled structure is far below the sampler's random order
+    f = opQ.bsr3(); rp = f.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(f.n, device=dev), rp[1:] - rp[:-1])
+    assert float((rows - f.col.long()).abs().float().mean()) < 0.2 * float(np.abs(np.repeat(np.arange(b["N"]), np.diff(b["rowptr"])) - b["col"]).mean())
+    plan = plan_chain(J=3)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(b["N"], 3, generator=g)
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    refP = co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F)
+    refQ = co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F)
+    for op in (opP, opT):
+        xg = x.to(dev).requires_grad_(True)
+        W = get_Batch_Wjxs(xg, op, J=3)
+        _close(W, refP)
+        gP = torch.randn(W.shape, generator=g)
+        W.backward(gP.to(dev))
+        _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T), rtol=2e-5)
+    xq = xv.to(dev).requires_grad_(True)
+    Wq = get_Batch_Wjxs(xq, opQ, J=3)
+    _close(Wq, refQ)
+    gQ = torch.randn(Wq.shape, generator=g)
+    Wq.backward(gQ.to(dev))
+    _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=2e-5)
+
+
 def test_register_path_long_rows_and_small_parts():
     """rows longer than the register capacity (DMAX) take the streamed tail; parts of many tiny graphs."""
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
