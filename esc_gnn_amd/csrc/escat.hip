@@ -1297,11 +1297,14 @@ static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_row
     if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "register-resident chain needs %zu B of LDS", lds);
     auto kern = k_chain_sell<Op, NT, BWD>;
     int rc = set_lds(kern, lds); if (rc) return rc;
-    static size_t cached_lds = (size_t)-1; static int cached_per_cu = 0;       // per instantiation
-    if (cached_lds != lds) {
+    // resident workgroups per CU: cached per instantiation, LDS size and device (thread_local: no locking needed)
+    static thread_local size_t cached_lds = (size_t)-1; static thread_local int cached_per_cu = 0, cached_dev = -1;
+    int dev_now = 0;
+    (void)hipGetDevice(&dev_now);
+    if (cached_lds != lds || cached_dev != dev_now) {
         int per = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, NT, lds) != hipSuccess || per < 1) per = 1;
-        cached_per_cu = per; cached_lds = lds;
+        cached_per_cu = per; cached_lds = lds; cached_dev = dev_now;
     }
     const int64_t resident = (int64_t)cached_per_cu * cu_count();
     const int grid = (int)(n_parts < resident ? n_parts : resident);           // persistent: one wave of workgroups

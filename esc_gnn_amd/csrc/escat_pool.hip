@@ -126,14 +126,44 @@ __device__ __forceinline__ float cos_of(const float (&a)[D], float na, const flo
     return dot / (na * nb);
 }
 
+// gathers the cosines of a segment into this thread's LDS column, four edges in flight at a time (the loads of one edge
+// depend on nothing but its index; issued one per loop trip they would cost a full L2/HBM latency each)
+template <int D>
+__device__ __forceinline__ void gather_cosines(const float *__restrict__ v, const int *__restrict__ src, int e0, int cnt, int W, int w,
+                                               const float (&a)[D], float nac, float *sv, int tid, float &sum, float &sq)
+{
+    for (int i0 = 0; i0 < cnt; i0 += 4) {
+        float b[4][D];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u < cnt ? i0 + u : cnt - 1;          // clamped: the extra lanes re-read the last edge
+            const float *pb = v + ((int64_t)src[e0 + i] * W + w) * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) b[u][c] = pb[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < cnt) {
+                float dot = 0.f, nb = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) { dot = fmaf(a[c], b[u][c], dot); nb = fmaf(b[u][c], b[u][c], nb); }
+                nb = sqrtf(nb); nb = nb > 1e-8f ? nb : 1e-8f;
+                const float x = dot / (nac * nb);
+                sv[(i0 + u) * POOL_NT + tid] = x; sum += x; sq += x * x;
+            }
+        }
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(POOL_NT)
 k_vinv_fwd(const float *__restrict__ v, const int *__restrict__ src, const int *__restrict__ seg_ptr, int64_t n_nodes, int W,
-           int stats, int n_levels, const int *__restrict__ k_table, int table_ld, float *__restrict__ out, int *__restrict__ arg)
+           int stats, int n_levels, const int *__restrict__ k_table, int table_ld, float *__restrict__ out, int *__restrict__ arg,
+           int cap)
 {
-    extern __shared__ float lds[];
+    extern __shared__ float lds[];                 // [cap][POOL_NT] values, then as many position bytes
     float *sv = lds;
-    unsigned char *sp = reinterpret_cast<unsigned char *>(lds + POOL_MAX_DEG * POOL_NT);
+    unsigned char *sp = reinterpret_cast<unsigned char *>(lds + cap * POOL_NT);
     const int tid = threadIdx.x;
     const int m = ((stats & ST_MEAN) ? 1 : 0) + ((stats & ST_MAX) ? 1 : 0) + ((stats & ST_MIN) ? 1 : 0) + ((stats & ST_VAR) ? 1 : 0) + n_levels;
     const int na = ((stats & ST_MAX) ? 1 : 0) + ((stats & ST_MIN) ? 1 : 0) + n_levels;
@@ -147,9 +177,9 @@ k_vinv_fwd(const float *__restrict__ v, const int *__restrict__ src, const int *
         const float nac = nrm > 1e-8f ? nrm : 1e-8f;
         const int e0 = seg_ptr[n], cnt = seg_ptr[n + 1] - e0;
         float sum = 0.f, sq = 0.f;
-        for (int i = 0; i < cnt; ++i) {
-            const float x = cos_of<D>(a, nac, v + ((int64_t)src[e0 + i] * W + w) * D);
-            sum += x; sq += x * x;
+        gather_cosines<D>(v, src, e0, cnt, W, w, a, nac, sv, tid, sum, sq);
+        for (int i = 0; i < cnt; ++i) {             // insertion sort in place, ascending; equal values keep edge order
+            const float x = sv[i * POOL_NT + tid];
             int j = i;
             while (j > 0 && sv[(j - 1) * POOL_NT + tid] > x) {
                 sv[j * POOL_NT + tid] = sv[(j - 1) * POOL_NT + tid]; sp[j * POOL_NT + tid] = sp[(j - 1) * POOL_NT + tid]; --j;
@@ -219,10 +249,7 @@ k_vinv_bwd(const float *__restrict__ v, const int *__restrict__ src, const int *
         if (cnt > 0) {
             const int *ar = arg + n * (int64_t)na * W + w;
             float sum = 0.f, sq = 0.f;
-            for (int i = 0; i < cnt; ++i) {
-                const float x = cos_of<D>(a, nac, v + ((int64_t)src[e0 + i] * W + w) * D);
-                sc[i * POOL_NT + tid] = x; sum += x; sq += x * x;
-            }
+            gather_cosines<D>(v, src, e0, cnt, W, w, a, nac, sc, tid, sum, sq);
             int s = 1;
             float gmean = 0.f, gvar = 0.f;
             if (stats & ST_MEAN) { gmean = go[(int64_t)s * W]; ++s; }
@@ -244,25 +271,36 @@ k_vinv_bwd(const float *__restrict__ v, const int *__restrict__ src, const int *
                 if (stats & ST_MIN) { sc[ar[(int64_t)sa * W] * POOL_NT + tid] += go[(int64_t)s_min * W]; ++sa; }
                 for (int l = 0; l < n_levels; ++l, ++sa) sc[ar[(int64_t)sa * W] * POOL_NT + tid] += go[(int64_t)(s_q + l) * W];
             }
-            for (int i = 0; i < cnt; ++i) {
-                const float gc = sc[i * POOL_NT + tid];
-                if (TWO_PASS) gedge[(int64_t)(e0 + i) * W + w] = gc;
-                if (gc == 0.f) continue;
-                // cos = <a,b> / (na nb): d/da = b/(na nb) - cos a/na^2 (second term only where |a| is not clamped), same for b
-                const int64_t jb = ((int64_t)src[e0 + i] * W + w) * D;
-                float b[D]; float nb = 0.f, dot = 0.f;
+            for (int i0 = 0; i0 < cnt; i0 += 4) {       // four edges in flight (see gather_cosines)
+                float b[4][D]; int64_t jb[4];
 #pragma unroll
-                for (int c = 0; c < D; ++c) { b[c] = v[jb + c]; nb = fmaf(b[c], b[c], nb); dot = fmaf(a[c], b[c], dot); }
-                nb = sqrtf(nb);
-                const bool b_free = nb > 1e-8f;
-                const float nbc = b_free ? nb : 1e-8f;
-                const float x = dot / (nac * nbc);
-                const float r = gc / (nac * nbc);
-                const float ka = a_free ? gc * x / (nac * nac) : 0.f, kb = b_free ? gc * x / (nbc * nbc) : 0.f;
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u < cnt ? i0 + u : cnt - 1;
+                    jb[u] = ((int64_t)src[e0 + i] * W + w) * D;
 #pragma unroll
-                for (int c = 0; c < D; ++c) {
-                    da[c] += r * b[c] - ka * a[c];
-                    if (!TWO_PASS) atomicAdd(dv + jb + c, r * a[c] - kb * b[c]);
+                    for (int c = 0; c < D; ++c) b[u][c] = v[jb[u] + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + u >= cnt) continue;
+                    const float gc = sc[(i0 + u) * POOL_NT + tid];
+                    if (TWO_PASS) gedge[(int64_t)(e0 + i0 + u) * W + w] = gc;
+                    if (gc == 0.f) continue;
+                    // cos = <a,b> / (na nb): d/da = b/(na nb) - cos a/na^2 (second term only where |a| is not clamped), same for b
+                    float nb = 0.f, dot = 0.f;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) { nb = fmaf(b[u][c], b[u][c], nb); dot = fmaf(a[c], b[u][c], dot); }
+                    nb = sqrtf(nb);
+                    const bool b_free = nb > 1e-8f;
+                    const float nbc = b_free ? nb : 1e-8f;
+                    const float x = dot / (nac * nbc);
+                    const float r = gc / (nac * nbc);
+                    const float ka = a_free ? gc * x / (nac * nac) : 0.f, kb = b_free ? gc * x / (nbc * nbc) : 0.f;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        da[c] += r * b[u][c] - ka * a[c];
+                        if (!TWO_PASS) atomicAdd(dv + jb[u] + c, r * a[c] - kb * b[u][c]);
+                    }
                 }
             }
         }
@@ -289,19 +327,29 @@ k_vinv_bwd_src(const float *__restrict__ v, const int *__restrict__ dst, const i
         nb = sqrtf(nb);
         const bool b_free = nb > 1e-8f;
         const float nbc = b_free ? nb : 1e-8f;
-        for (int p = p0; p < p1; ++p) {
-            const int e = out_edge[p];
-            const float gc = gedge[(int64_t)e * W + w];
-            if (gc == 0.f) continue;
-            const float *pa = v + ((int64_t)dst[e] * W + w) * D;
-            float a[D]; float na = 0.f, dot = 0.f;
+        for (int q0 = p0; q0 < p1; q0 += 4) {
+            float av[4][D], gcs[4];
 #pragma unroll
-            for (int c = 0; c < D; ++c) { a[c] = pa[c]; na = fmaf(a[c], a[c], na); dot = fmaf(a[c], b[c], dot); }
-            na = sqrtf(na); na = na > 1e-8f ? na : 1e-8f;
-            const float x = dot / (na * nbc);
-            const float r = gc / (na * nbc), kb = b_free ? gc * x / (nbc * nbc) : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int e = out_edge[q0 + u < p1 ? q0 + u : p1 - 1];
+                gcs[u] = gedge[(int64_t)e * W + w];
+                const float *pa = v + ((int64_t)dst[e] * W + w) * D;
 #pragma unroll
-            for (int c = 0; c < D; ++c) db[c] += r * a[c] - kb * b[c];
+                for (int c = 0; c < D; ++c) av[u][c] = pa[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float gc = gcs[u];
+                if (q0 + u >= p1 || gc == 0.f) continue;
+                float na = 0.f, dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) { na = fmaf(av[u][c], av[u][c], na); dot = fmaf(av[u][c], b[c], dot); }
+                na = sqrtf(na); na = na > 1e-8f ? na : 1e-8f;
+                const float x = dot / (na * nbc);
+                const float r = gc / (na * nbc), kb = b_free ? gc * x / (nbc * nbc) : 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) db[c] += r * av[u][c] - kb * b[c];
+            }
         }
 #pragma unroll
         for (int c = 0; c < D; ++c) dv[g * D + c] += db[c];
@@ -323,13 +371,10 @@ extern "C" int escat_neighbor_pool_f32(const float *vals, const int32_t *seg_ptr
     if (n_levels > 0 && !k_table) return escat_fail(ESCAT_EINVAL, "k_table is NULL");
     if (max_deg > POOL_MAX_DEG) return escat_fail(ESCAT_ERANGE, "max_deg=%d: at most %d incoming edges per node", max_deg, POOL_MAX_DEG);
     if (n_nodes <= 0) return n_nodes == 0 ? ESCAT_OK : escat_fail(ESCAT_EINVAL, "negative n_nodes");
-    static bool attr_set = false;
     const size_t lds = (size_t)POOL_MAX_DEG * POOL_NT * 5;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_pool_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return escat_fail(ESCAT_ELAUNCH, "hipFuncSetAttribute(k_pool_fwd)");
-        attr_set = true;
-    }
+    // (set on every call: the attribute is per device and the call costs microseconds)
+    if (hipFuncSetAttribute((const void *)k_pool_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return escat_fail(ESCAT_ELAUNCH, "hipFuncSetAttribute(k_pool_fwd)");
     hipLaunchKernelGGL(k_pool_fwd, dim3(pool_grid(n_nodes * W)), dim3(POOL_NT), lds, (hipStream_t)stream, vals, seg_ptr, n_nodes, W,
                        stats, n_levels, k_table, POOL_MAX_DEG + 1, out, arg);
     hipError_t e = hipGetLastError();
@@ -362,25 +407,23 @@ extern "C" int escat_vector_invariants_f32(const float *v, const int32_t *src, c
     if (n_levels > 0 && !k_table) return escat_fail(ESCAT_EINVAL, "k_table is NULL");
     if (max_deg > POOL_MAX_DEG) return escat_fail(ESCAT_ERANGE, "max_deg=%d: at most %d incoming edges per node", max_deg, POOL_MAX_DEG);
     if (n_nodes <= 0) return n_nodes == 0 ? ESCAT_OK : escat_fail(ESCAT_EINVAL, "negative n_nodes");
-    const size_t lds = (size_t)POOL_MAX_DEG * POOL_NT * 5;
-    static bool attr2 = false, attr3 = false;
-    bool &done = d == 2 ? attr2 : attr3;
-    if (!done) {
+    const int cap = max_deg < 4 ? 4 : (max_deg + 3) & ~3;           // LDS column height: as low as the graph allows (occupancy)
+    const size_t lds = (size_t)cap * POOL_NT * 5;
+    {
         hipError_t e = d == 2 ? hipFuncSetAttribute((const void *)k_vinv_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                               : hipFuncSetAttribute((const void *)k_vinv_fwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return escat_fail(ESCAT_ELAUNCH, "hipFuncSetAttribute(k_vinv_fwd)");
-        done = true;
     }
     const int grid = pool_grid(n_nodes * W);
-    if (d == 2) hipLaunchKernelGGL(k_vinv_fwd<2>, dim3(grid), dim3(POOL_NT), lds, (hipStream_t)stream, v, src, seg_ptr, n_nodes, W, stats, n_levels, k_table, POOL_MAX_DEG + 1, out, arg);
-    else        hipLaunchKernelGGL(k_vinv_fwd<3>, dim3(grid), dim3(POOL_NT), lds, (hipStream_t)stream, v, src, seg_ptr, n_nodes, W, stats, n_levels, k_table, POOL_MAX_DEG + 1, out, arg);
+    if (d == 2) hipLaunchKernelGGL(k_vinv_fwd<2>, dim3(grid), dim3(POOL_NT), lds, (hipStream_t)stream, v, src, seg_ptr, n_nodes, W, stats, n_levels, k_table, POOL_MAX_DEG + 1, out, arg, cap);
+    else        hipLaunchKernelGGL(k_vinv_fwd<3>, dim3(grid), dim3(POOL_NT), lds, (hipStream_t)stream, v, src, seg_ptr, n_nodes, W, stats, n_levels, k_table, POOL_MAX_DEG + 1, out, arg, cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return escat_fail(ESCAT_ELAUNCH, "k_vinv_fwd: %s", hipGetErrorString(e));
     return ESCAT_OK;
 }
 
 extern "C" int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const int32_t *seg_ptr, int64_t n_nodes, int W,
-                                               int d, int stats, int n_levels, const float *gout, const int32_t *arg, float *dv,
+                                               int d, int max_deg, int stats, int n_levels, const float *gout, const int32_t *arg, float *dv,
                                                const int32_t *dst, const int32_t *out_ptr, const int32_t *out_edge, float *gedge,
                                                void *stream)
 {
@@ -392,16 +435,13 @@ extern "C" int escat_vector_invariants_bwd_f32(const float *v, const int32_t *sr
     if (n_nodes <= 0) return n_nodes == 0 ? ESCAT_OK : escat_fail(ESCAT_EINVAL, "negative n_nodes");
     const bool two = gedge != nullptr;
     if (two && (!dst || !out_ptr || !out_edge)) return escat_fail(ESCAT_EINVAL, "the two-pass form needs dst, out_ptr and out_edge");
-    const size_t lds = (size_t)POOL_MAX_DEG * POOL_NT * 4;
-    static bool done[4] = {false, false, false, false};
+    if (max_deg > POOL_MAX_DEG) return escat_fail(ESCAT_ERANGE, "max_deg=%d: at most %d incoming edges per node", max_deg, POOL_MAX_DEG);
+    const size_t lds = (size_t)(max_deg < 4 ? 4 : (max_deg + 3) & ~3) * POOL_NT * 4;
     const int which = (d == 2 ? 0 : 1) + (two ? 2 : 0);
     const void *fn = which == 0 ? (const void *)k_vinv_bwd<2, false> : which == 1 ? (const void *)k_vinv_bwd<3, false>
                    : which == 2 ? (const void *)k_vinv_bwd<2, true> : (const void *)k_vinv_bwd<3, true>;
-    if (!done[which]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return escat_fail(ESCAT_ELAUNCH, "hipFuncSetAttribute(k_vinv_bwd)");
-        done[which] = true;
-    }
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return escat_fail(ESCAT_ELAUNCH, "hipFuncSetAttribute(k_vinv_bwd)");
     const int grid = pool_grid(n_nodes * W);
     hipStream_t st = (hipStream_t)stream;
 #define GO(DD, TP) hipLaunchKernelGGL((k_vinv_bwd<DD, TP>), dim3(grid), dim3(POOL_NT), lds, st, v, src, seg_ptr, n_nodes, W, stats, n_levels, gout, arg, dv, gedge)

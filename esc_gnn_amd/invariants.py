@@ -131,7 +131,7 @@ class _VectorInvariants(torch.autograd.Function):
         dv = torch.empty_like(v)
         gedge = torch.empty(max(eg.n_edges, 1) * W, dtype=torch.float32, device=v.device)     # two-pass form: no atomics
         with torch.cuda.device(v.device):
-            rc = lib.escat_vector_invariants_bwd_f32(_ptr(v), _ptr(eg.src_s), _ptr(eg.seg_ptr), N, W, d, stats, n_levels,
+            rc = lib.escat_vector_invariants_bwd_f32(_ptr(v), _ptr(eg.src_s), _ptr(eg.seg_ptr), N, W, d, eg.max_deg, stats, n_levels,
                                                      _ptr(gout.contiguous()), _ptr(arg), _ptr(dv), _ptr(eg.dst_s),
                                                      _ptr(eg.out_ptr), _ptr(eg.out_edge), ctypes.c_void_p(gedge.data_ptr()),
                                                      _stream(v.device))

@@ -262,7 +262,7 @@ int escat_vector_invariants_f32(const float *v, const int32_t *src, const int32_
  *    grouped by source: dst[e] = destination of edge e (in the destination-grouped order the forward used),
  *    out_edge[out_ptr[n] .. out_ptr[n+1]) = the edges e whose source is node n. */
 int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const int32_t *seg_ptr, int64_t n_nodes, int W, int d,
-                                    int stats, int n_levels, const float *gout, const int32_t *arg, float *dv,
+                                    int max_deg, int stats, int n_levels, const float *gout, const int32_t *arg, float *dv,
                                     const int32_t *dst, const int32_t *out_ptr, const int32_t *out_edge, float *gedge,
                                     void *stream);
 
