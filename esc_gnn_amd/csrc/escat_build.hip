@@ -394,3 +394,36 @@ extern "C" int escat_build_Q_bsr3(const int32_t *rowptr, const int32_t *col, con
     CHECK_LAUNCH("escat_build_Q_bsr3");
     return ESCAT_OK;
 }
+
+// ------------------------------------------------------------------ host utility: Jenkins lookup3 (hashlittle)
+// the checksum of HDF5's version-2 object headers and superblock (esc_gnn_amd/hdf5_min.py writes ~2e5 of them for a
+// cfg5 dataset; the pure-Python form there stays as the reference the known-answer vectors are checked against)
+static inline uint32_t rot32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+extern "C" uint32_t escat_lookup3(const uint8_t *data, size_t n, uint32_t initval)
+{
+    uint32_t a, b, c;
+    a = b = c = 0xdeadbeefu + (uint32_t)n + initval;
+    auto rd = [](const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    while (n > 12) {
+        a += rd(data); b += rd(data + 4); c += rd(data + 8);
+        a -= c; a ^= rot32(c, 4);  c += b;
+        b -= a; b ^= rot32(a, 6);  a += c;
+        c -= b; c ^= rot32(b, 8);  b += a;
+        a -= c; a ^= rot32(c, 16); c += b;
+        b -= a; b ^= rot32(a, 19); a += c;
+        c -= b; c ^= rot32(b, 4);  b += a;
+        data += 12; n -= 12;
+    }
+    if (n == 0) return c;
+    uint8_t tail[12] = {0};
+    for (size_t i = 0; i < n; ++i) tail[i] = data[i];
+    a += rd(tail); b += rd(tail + 4); c += rd(tail + 8);
+    c ^= b; c -= rot32(b, 14);
+    a ^= c; a -= rot32(c, 11);
+    b ^= a; b -= rot32(a, 25);
+    c ^= b; c -= rot32(b, 16);
+    a ^= c; a -= rot32(c, 4);
+    b ^= a; b -= rot32(a, 14);
+    c ^= b; c -= rot32(b, 24);
+    return c;
+}

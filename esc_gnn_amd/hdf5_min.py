@@ -29,7 +29,26 @@ def _rot(x, k):
     return ((x << k) | (x >> (32 - k))) & 0xFFFFFFFF
 
 
+_fast_lookup3 = None
+
+
 def lookup3(data: bytes, initval: int = 0) -> int:
+    """libescat's C form when the library is built (100x faster: a dataset file has ~1e5 headers); lookup3_py is the
+    same function in plain Python, kept as the form the known-answer vectors are pinned on."""
+    global _fast_lookup3
+    if _fast_lookup3 is None:
+        try:
+            from . import _lib
+            _fast_lookup3 = _lib.load().escat_lookup3
+        except Exception:
+            _fast_lookup3 = False
+    if _fast_lookup3:
+        data = bytes(data)
+        return int(_fast_lookup3(data, len(data), initval))
+    return lookup3_py(data, initval)
+
+
+def lookup3_py(data: bytes, initval: int = 0) -> int:
     M = 0xFFFFFFFF
     n = len(data)
     a = b = c = (0xdeadbeef + n + initval) & M
@@ -198,6 +217,7 @@ class H5Reader:
         if struct.unpack("<I", b[44:48])[0] != lookup3(b[:44]):
             raise ValueError("superblock checksum mismatch")
         self.eof, self.root = struct.unpack("<QQ", b[28:44])
+        self._nodes = {}                # parsed object headers by address (a group with 1e5 links is parsed once)
 
     def _messages(self, addr: int):
         b = self.buf
@@ -220,6 +240,12 @@ class H5Reader:
         return out
 
     def node(self, addr: int):
+        hit = self._nodes.get(addr)
+        if hit is None:
+            hit = self._nodes[addr] = self._parse_node(addr)
+        return hit
+
+    def _parse_node(self, addr: int):
         msgs = self._messages(addr)
         types = [m[0] for m in msgs]
         if 0x02 in types:

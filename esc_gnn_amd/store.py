@@ -24,12 +24,13 @@ def load_operator_store(path: str, device, indices: Optional[Sequence[int]] = No
     try:
         ids = sorted((int(k) for k in f["P"].keys())) if indices is None else [int(i) for i in indices]
         out = {}
-        sizes = [int(f["P"][str(i)]["size"][...][0]) for i in ids]
+        gP, gQ = f["P"], f["Q"]
+        sizes = [int(gP[str(i)]["size"][...][0]) for i in ids]
         gp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         for key, unit in (("P", 1), ("Q", 3)):
             rows, cols, vals = [], [], []
             for g, i in enumerate(ids):
-                grp = f[key][str(i)]
+                grp = (gP if key == "P" else gQ)[str(i)]
                 idx = np.asarray(grp["indices"][...], dtype=np.int64)
                 if tuple(int(v) for v in grp["size"][...]) != (unit * sizes[g], unit * sizes[g]):
                     raise ValueError(f"escat: {key}/{i} has size {grp['size'][...]} but P/{i} has {sizes[g]} nodes")

@@ -266,6 +266,10 @@ int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const in
                                     const int32_t *dst, const int32_t *out_ptr, const int32_t *out_edge, float *gedge,
                                     void *stream);
 
+/* host utility (no GPU): Jenkins lookup3 "hashlittle", the checksum of HDF5 version-2 object headers
+ * (esc_gnn_amd/hdf5_min.py, the writer of the reference's operator layout). */
+uint32_t escat_lookup3(const uint8_t *data, size_t n, uint32_t initval);
+
 #ifdef __cplusplus
 }
 #endif

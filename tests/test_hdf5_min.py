@@ -12,7 +12,15 @@ from esc_gnn_amd import hdf5_min as h5
 
 
 def test_lookup3_vectors():
-    # from Bob Jenkins' lookup3.c self-test (driver5)
+    # from Bob Jenkins' lookup3.c self-test (driver5); both forms: plain Python and libescat's C
+    assert h5.lookup3_py(b"") == 0xdeadbeef
+    s0 = b"Four score and seven years ago"
+    assert h5.lookup3_py(s0, 0) == 0x17770551 and h5.lookup3_py(s0, 1) == 0xcd628161
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 11, 12, 13, 24, 25, 1000):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert h5.lookup3(d, 7) == h5.lookup3_py(d, 7)
     assert h5.lookup3(b"") == 0xdeadbeef
     s = b"Four score and seven years ago"
     assert h5.lookup3(s, 0) == 0x17770551
