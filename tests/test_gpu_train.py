@@ -22,6 +22,9 @@ def test_dp_train_step_learns():
     torch.manual_seed(0)
     tr = DPTrainer(C=3, diffusion_kwargs=dict(scales_type="dyadic", J=3, include_lowpass=True), device=dev)
     assert 5e4 < tr.n_params() < 2e5
-    losses = [float(tr.step(pos, pos, b["P"], b["Q"], gid, B, target).detach()) for _ in range(25)]
+    pc = b["P"].csr(); rp = pc.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(pc.n, device=dev), rp[1:] - rp[:-1]); cols = pc.col.long()
+    edge_index = torch.stack([cols[rows != cols], rows[rows != cols]])               # (src, dst), no self loops
+    losses = [float(tr.step(pos, pos, b["P"], b["Q"], gid, B, target, edge_index).detach()) for _ in range(25)]
     assert all(np.isfinite(losses)) and losses[-1] < 0.2 * losses[0]
     assert all(p.grad.data_ptr() >= tr.bucket.flat.data_ptr() for p in tr.model.parameters())   # grads alias the bucket

@@ -31,6 +31,11 @@ def main():
     gp = torch.arange(args.graphs + 1, dtype=torch.int32, device=dev) * args.nodes
     b = build_PQ_batch(pos, gp, args.k, {"kernel": "gaussian", "gaussian_eps": 0.05}, max_graph_nodes=args.nodes)
     graph_id = torch.arange(args.graphs, device=dev).repeat_interleave(args.nodes)
+    # edge_index of the batch (no self loops), as batch.edge_index in the reference: (src, dst) = (col, row) of P's pattern
+    pc = b["P"].csr(); rp = pc.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(pc.n, device=dev), rp[1:] - rp[:-1]); cols = pc.col.long()
+    off = rows != cols
+    edge_index = torch.stack([cols[off], rows[off]])
     # synthetic graph-level target: the cloud's diameter-like extent (max coordinate range)
     target = torch.from_numpy((clouds.max(1) - clouds.min(1)).max(1).astype(np.float32)).to(dev)
     torch.manual_seed(0)          # identical initial weights on every rank
@@ -38,12 +43,12 @@ def main():
     b["P"].csr().sell(); b["Q"].bsr3().sell()
     losses = []
     for _ in range(args.warmup):
-        tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target)
+        tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target, edge_index)
     if world > 1: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target))
+        losses.append(tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target, edge_index))
     if world > 1: dist.barrier()
     torch.cuda.synchronize()
     dt = max_over_ranks(time.perf_counter() - t0, dev)
