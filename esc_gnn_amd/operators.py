@@ -388,7 +388,11 @@ class ScatterOperator:
                 A = A.to_sparse_coo().coalesce()
                 rows, col, val = A.indices()[0], A.indices()[1], A.values()
         elif A.layout == torch.sparse_coo:
+            fast = None
             if not A.is_coalesced():
+                fast = ScatterOperator._from_emission_order(A, n, graph_ptr)
+                if fast is not None:
+                    return fast
                 A = A.coalesce()
             rows, col, val = A.indices()[0], A.indices()[1], A.values()
         else:
@@ -400,6 +404,52 @@ class ScatterOperator:
             if int(op._graph_ptr[-1]) != n or int(op._graph_ptr[0]) != 0:
                 raise ValueError("escat: graph_ptr must run from 0 to the operator size")
         if n % 3 == 0 and op._coo[0].numel() > 0:
+            op._try_bsr3()
+        op._reorder_if_large()
+        return op
+
+    @staticmethod
+    def _from_emission_order(A: torch.Tensor, n: int, graph_ptr=None):
+        """
+        Sort-free ingest of the two layouts the reference's pipeline actually produces (the tensors are flagged
+        un-coalesced although they hold no duplicates, and torch.sparse.mm re-sorts them on every call):
+          * P: indices already row-major sorted (process_pyg_data.py:775 coalesces per sample; the collate adds offsets);
+          * Q: "block-emission order" (process_pyg_data.py:839-857): entries come in groups of nine, the 3x3 block of one
+            P-nonzero (i, j) row-major, blocks in P's order -- never sorted by scalar row, never coalesced (:863-868).
+        One elementwise pass checks the pattern (a single host sync); on success CSR / BSR-3 is formed directly.
+        Returns None when the tensor is anything else (the caller then coalesces).
+        """
+        idx, val = A._indices(), A._values()
+        nnz = int(idx.shape[1])
+        if nnz == 0:
+            return None
+        dev = A.device
+        r, c = idx[0], idx[1]
+        if n % 3 == 0 and nnz % 9 == 0:
+            r9, c9 = r.view(-1, 9), c.view(-1, 9)
+            a = torch.arange(3, device=dev)
+            br, bc = r9[:, 0] // 3, c9[:, 0] // 3
+            ok = (r9 == (3 * br)[:, None] + a.repeat_interleave(3)[None, :]).all() & (c9 == (3 * bc)[:, None] + a.repeat(3)[None, :]).all()
+            nb = n // 3
+            key = br * nb + bc
+            ok = ok & (key[1:] > key[:-1]).all() if key.numel() > 1 else ok
+            if bool(ok):
+                op = ScatterOperator(n, dev)
+                if graph_ptr is not None:
+                    op._graph_ptr = torch.as_tensor(graph_ptr, device=dev).to(torch.int64)
+                parts = op._parts_for(3) if op._graph_ptr is not None and bool((op._graph_ptr % 3 == 0).all()) else None
+                op._bsr = _Csr(_rowptr(br, nb), bc.to(torch.int32).contiguous(), val.to(torch.float32).reshape(-1, 3, 3).contiguous(), nb, parts)
+                op.bsr_fill = 1.0
+                op._reorder_if_large()
+                return op
+        key = r * n + c
+        if key.numel() > 1 and not bool((key[1:] > key[:-1]).all()):
+            return None
+        op = ScatterOperator(n, dev)
+        if graph_ptr is not None:
+            op._graph_ptr = torch.as_tensor(graph_ptr, device=dev).to(torch.int64)
+        op._coo = (r.long(), c.long(), val.to(torch.float32))
+        if n % 3 == 0:
             op._try_bsr3()
         op._reorder_if_large()
         return op

@@ -212,3 +212,33 @@ def test_operator_batch_view_index_logic():
     blk = torch.eye(3).repeat(n, 1, 1)
     q = ScatterOperator.from_bsr3(rowptr, col, blk, n, parts=ScatterOperator.parts_from_graph_ptr(gp)).select([1])
     assert q.n == 9 and q.row_index().tolist() == list(range(6, 15))
+
+
+def test_sort_free_ingest_of_reference_layouts():
+    """from_torch on the layouts the reference produces (row-major P, block-emission-order Q, both flagged
+    un-coalesced) skips the sort and still gives the canonical structure of the coalesce path; anything else falls back."""
+    import numpy as np
+    import torch
+    from esc_gnn_amd import synthetic, ScatterOperator
+    b = synthetic.ellipsoid_batch(6, 50, 5, seed=3)
+    N = b["N"]; rows = np.repeat(np.arange(N), np.diff(b["rowptr"])); cols = b["col"].astype(np.int64)
+    a = np.arange(3)
+    qr = ((3 * rows)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1)
+    qc = ((3 * cols)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1)
+    Q = torch.sparse_coo_tensor(torch.from_numpy(np.stack([qr, qc])), torch.from_numpy(b["blk"].reshape(-1)), (3 * N, 3 * N))
+    P = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(b["pval"]), (N, N))
+    assert not Q.is_coalesced() and not P.is_coalesced()
+    assert ScatterOperator._from_emission_order(Q, 3 * N) is not None and ScatterOperator._from_emission_order(P, N) is not None
+    fq, fp = ScatterOperator.from_torch(Q, allow_cpu=True), ScatterOperator.from_torch(P, allow_cpu=True)
+    sq, sp = ScatterOperator.from_torch(Q.coalesce(), allow_cpu=True), ScatterOperator.from_torch(P.coalesce(), allow_cpu=True)
+    for x, y in ((fq.bsr3(), sq.bsr3()), (fp.csr(), sp.csr()), (fq.csr(), sq.csr())):
+        assert torch.equal(x.rowptr, y.rowptr) and torch.equal(x.col, y.col) and torch.equal(x.val, y.val)
+        assert torch.equal(x.part_ptr, y.part_ptr)
+    perm = torch.randperm(Q._nnz(), generator=torch.Generator().manual_seed(0))
+    Qs = torch.sparse_coo_tensor(Q._indices()[:, perm], Q._values()[perm], Q.shape)
+    assert ScatterOperator._from_emission_order(Qs, 3 * N) is None
+    assert torch.equal(ScatterOperator.from_torch(Qs, allow_cpu=True).bsr3().val, sq.bsr3().val)
+    # duplicates must not take the fast path (coalesce sums them)
+    Pd = torch.sparse_coo_tensor(torch.tensor([[0, 0, 1], [0, 0, 1]]), torch.tensor([1.0, 2.0, 3.0]), (2, 2))
+    assert ScatterOperator._from_emission_order(Pd, 2) is None
+    assert ScatterOperator.from_torch(Pd, allow_cpu=True).csr().val.tolist() == [3.0, 3.0]
