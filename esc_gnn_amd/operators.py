@@ -601,6 +601,8 @@ class OperatorBatch:
     """
 
     def __init__(self, base: ScatterOperator, part_ids):
+        if base.row_perm is not None:
+            raise ValueError("escat: a locality-relabelled operator (one large connected block) cannot be batched by parts")
         self.base = base
         self.device = base.device
         ids = torch.as_tensor(part_ids, device=base.device).to(torch.int64).flatten()
