@@ -29,7 +29,8 @@ class EscatSell(ctypes.Structure):
                 ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("slices_per_part", ctypes.c_int32),
                 ("reserved", ctypes.c_int32),
                 ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p),
-                ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32)]
+                ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32),
+                ("orders", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/escat.h declares

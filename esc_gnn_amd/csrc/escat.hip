@@ -541,6 +541,7 @@ struct SellDev {
     const float *val; const unsigned *lc; const int *lane_meta;
     const int *part_list, *part_row0;             // optional: the launch covers parts part_list[i], whose rows of the
     int dmax, nsl;                                // dense operands start at part_row0[i] (a batch drawn from a store)
+    int orders;                                   // forward only: 0 = the bank; 1 = [x | bank]; 2 = [x | bank | pair products]
 };
 
 #define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
@@ -739,10 +740,13 @@ __device__ __forceinline__ void dma_in(float *dst, const float *__restrict__ src
 
 // builds the first vector of a part from its staged input (fwd: x in `inb`; bwd: the upstream-gradient slab), applies
 // the step-0 events (fwd) / forms the Horner start (bwd); returns the event cursor.  Ends with a barrier.
+// Fs / so: row stride of the slab and offset of slot 0 in it (Fs = F, so = 0; the fused-orders forward keeps x itself
+// in front of each row's bank: Fs = F + 1, so = 1).
 template <bool BWD, int NT>
 __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab, const float *inb, int rows, int R, int C, int CP,
-                                              int F, int T, const EvTable &tab)
+                                              int F, int T, const EvTable &tab, int Fs = -1, int so = 0)
 {
+    if (Fs < 0) Fs = F;
     const int tid = threadIdx.x;
     const int nc = rows * C;
     int p;
@@ -753,8 +757,9 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab,
             const int c = i % C, r = i / C; const float y = inb[i];
             xa[r * CP + c] = y;
             xa[(R + sell_copyB(r, R)) * CP + c] = y;
+            if (so) slab[i * Fs] = y;
             for (int k = 0; k < p1; ++k)
-                if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * F, y, tab.e[k].slot, tab.e[k].sign);
+                if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * Fs + so, y, tab.e[k].slot, tab.e[k].sign);
         }
         p = p1;
     } else {
@@ -787,6 +792,39 @@ __device__ __forceinline__ void chain_epilogue(const float *xa, const float *sla
     }
 }
 
+// forward epilogue with the orders 0/1/2 of ESCGNNModular._scatter fused in (models/escgnn_modular.py:333-341): writes
+// (rows*C, Wtot) = [x | bank | bank_i * bank_j, i < j in triu order] straight from the LDS slab, so the bank itself
+// never goes to HBM and back.  The slab rows are [x | bank] in this mode (chain_prologue puts x there).
+// One thread per row-channel expands its slab row [x | bank] to Wtot values in an LDS tile (the two vector buffers are
+// dead by now), then the tile goes out as a contiguous run; no per-element index arithmetic.
+template <int NT>
+__device__ __forceinline__ void chain_epilogue_orders(const float *slab, float *tile, int tile_floats, float *__restrict__ RES,
+                                                      int64_t first_row, int rows, int C, int F, int second)
+{
+    const int wtot = 1 + F + (second ? F * (F - 1) / 2 : 0), Fs = F + 1;
+    const int nrc = rows * C, per = tile_floats / wtot;
+    float *og = RES + first_row * C * wtot;
+    for (int c0 = 0; c0 < nrc; c0 += per) {
+        const int n = nrc - c0 < per ? nrc - c0 : per;
+        for (int rc = threadIdx.x; rc < n; rc += NT) {
+            const float *srow = slab + (c0 + rc) * Fs;
+            float *o = tile + rc * wtot;
+            for (int f = 0; f <= F; ++f) o[f] = srow[f];
+            if (second) {
+                int q = 1 + F;
+                for (int i = 0; i < F; ++i) {
+                    const float a = srow[1 + i];
+                    for (int j = i + 1; j < F; ++j) o[q++] = a * srow[1 + j];
+                }
+            }
+        }
+        __syncthreads();
+        float *dst = og + (int64_t)c0 * wtot;
+        for (int i = threadIdx.x; i < n * wtot; i += NT) dst[i] = tile[i];
+        __syncthreads();
+    }
+}
+
 // ---- the register-resident chain kernel: persistent workgroups, software-pipelined over parts.
 // A workgroup walks parts blockIdx.x, + gridDim.x, ...  While part g steps, the metadata of part g' = g + gridDim.x
 // is fetched (one 12-B load per lane) and its input is copied into LDS by DMA; the moment g's last step is done --
@@ -803,7 +841,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
     constexpr int C = Op::C, CP = Op::CP;
     extern __shared__ __align__(16) float smem[];
     const int nv = 2 * sell_padR(max_rows) * CP;                 // two copies per vector, a multiple of 32 floats
-    const int slab_sz = (max_rows * C * F + 3) & ~3;
+    const int so = (!BWD && sd.orders) ? 1 : 0, Fs = F + so;    // fused orders: slab rows are [x | bank]
+    const int slab_sz = (max_rows * C * Fs + 3) & ~3;
     float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
     float *inb = (BWD && !early) ? slab : slab + slab_sz;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -840,7 +879,10 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         op.load(sd, doff, poff, w, lane);
         STAMP(li, 1);
         // ... and store the previous part's result underneath the stream
-        if (prev_rows >= 0) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+        if (prev_rows >= 0) {
+            if (!BWD && sd.orders) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
+            else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+        }
         STAMP(li, 2);
 
         const int R = sell_padR(rows);
@@ -853,7 +895,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         if (prev_rows < 0 || (BWD && !early)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                          // every wave's copy has landed; the epilogue's LDS reads are done
         STAMP(li, 3);
-        int p = chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab);
+        int p = chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab, Fs, so);
         STAMP(li, 4);
 
         int rtN = 0, te0N = 0, swN = 0;
@@ -881,7 +923,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
 #pragma unroll
                 for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
 #pragma unroll
-                for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * F);
+                for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
                 y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
             }
 #ifdef ESCAT_STAMPS
@@ -913,7 +955,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         li = liN; part = partN; row0 = row0N; rt = rtN; te0 = te0N; sw = swN;
         if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
     }
-    chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+    if (!BWD && sd.orders) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
+    else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
 }
 
 // ------------------------------------------------------------------ pack-time slot planning
@@ -1245,7 +1288,7 @@ static int chain_path_override()
     return 0;
 }
 
-#define LIST_NEEDS_REG "escat_sell.part_list needs the register-resident path (a packed operator whose parts have <= 512 rows and fit LDS)"
+#define LIST_NEEDS_REG "escat_sell.part_list / .orders need the register-resident path (a packed operator whose parts have <= 512 rows and fit LDS)"
 
 static int sell_to_dev(const escat_sell *sell, SellDev *sd)
 {
@@ -1257,6 +1300,8 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
         return fail(ESCAT_EINVAL, "escat_sell.part_list and part_row0 go together (n_list >= 0)");
     sd->val = sell->val; sd->lc = sell->lc; sd->lane_meta = sell->lane_meta; sd->dmax = sell->dmax; sd->nsl = sell->slices_per_part;
     sd->part_list = sell->part_list; sd->part_row0 = sell->part_row0;
+    if (sell->orders < 0 || sell->orders > 2) return fail(ESCAT_EINVAL, "escat_sell.orders=%d: 0, 1 or 2", sell->orders);
+    sd->orders = sell->orders;
     return ESCAT_OK;
 }
 
@@ -1274,10 +1319,10 @@ static int cu_count()
 
 // LDS of a k_chain_sell workgroup: two vectors of two copies, the slab, and the staged input (fwd: x; bwd: a second
 // slab if `want` workgroups per CU still fit -- *early = 1 -- else none)
-static size_t sell_lds_bytes(int C, int CP, int max_rows, int F, bool bwd, int want, int *early)
+static size_t sell_lds_bytes(int C, int CP, int max_rows, int F, bool bwd, int want, int *early, int orders = 0)
 {
     const size_t nv = (size_t)2 * sell_padR(max_rows) * CP;
-    const size_t slab = ((size_t)max_rows * C * F + 3) & ~(size_t)3;
+    const size_t slab = ((size_t)max_rows * C * (F + (!bwd && orders ? 1 : 0)) + 3) & ~(size_t)3;
     const size_t base = (2 * nv + slab) * sizeof(float);
     if (!bwd) { *early = 1; return base + ((((size_t)max_rows * C + 3) & ~(size_t)3)) * sizeof(float); }
     const size_t two = base + slab * sizeof(float);
@@ -1293,7 +1338,7 @@ static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_row
     if (sd.nsl * 64 != NT) return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d does not match parts of <= %d rows", sd.nsl, max_rows);
     int early = 0;
     const int want = Op::MINW == 1 ? 1 : (NT == 512 ? 2 : 4);
-    const size_t lds = sell_lds_bytes(Op::C, Op::CP, max_rows, F, BWD, want, &early);
+    const size_t lds = sell_lds_bytes(Op::C, Op::CP, max_rows, F, BWD, want, &early, sd.orders);
     if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "register-resident chain needs %zu B of LDS", lds);
     auto kern = k_chain_sell<Op, NT, BWD>;
     int rc = set_lds(kern, lds); if (rc) return rc;
@@ -1387,12 +1432,13 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
         if (lds <= LDS_BUDGET) {
             const int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
             int early_ = 0;
-            const size_t lds_s = sell_lds_bytes(C, CP, max_part_rows, F, BWD, max_part_rows <= 256 ? 4 : 2, &early_);
+            const size_t lds_s = sell_lds_bytes(C, CP, max_part_rows, F, BWD, max_part_rows <= 256 ? 4 : 2, &early_, sell ? sell->orders : 0);
             if (max_part_rows <= 512 && sell && force != 2 && lds_s <= LDS_BUDGET) {
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
+                if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
                 rc = launch_csr_sell<BWD>(C, max_part_rows, col, val, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
-            } else if (sell && sell->part_list)
+            } else if (sell && (sell->part_list || sell->orders))
                 return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
             else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
@@ -1401,7 +1447,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
             return ESCAT_OK;
         }
     }
-    if (sell && sell->part_list) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
+    if (sell && (sell->part_list || sell->orders)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
     // multi-launch path
     const size_t need = (size_t)2 * n * C * sizeof(float);
     if (T > 0 && (!workspace || workspace_bytes < need))
@@ -1477,16 +1523,17 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
     if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3) {
         const size_t lds = (size_t)max_part_rows * 3 * (2 + F) * sizeof(float);
         int early_ = 0;
-        const size_t lds_s = sell_lds_bytes(3, 4, max_part_rows, F, BWD, 1, &early_);
+        const size_t lds_s = sell_lds_bytes(3, 4, max_part_rows, F, BWD, 1, &early_, sell ? sell->orders : 0);
         if (lds <= LDS_BUDGET && lds_s <= LDS_BUDGET && max_part_rows <= 512 && sell && force != 2) {
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
+            if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
             rc = launch_bsr3_sell<BWD>(max_part_rows, col, blk, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_bsr3_sell");
             return ESCAT_OK;
         }
-        if (sell && sell->part_list) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
+        if (sell && (sell->part_list || sell->orders)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
         if (lds <= LDS_BUDGET) {
 #define GO(gg)                                                                                          \
             rc = set_lds(k_chain_bsr3<gg, BWD>, lds); if (rc) return rc;                                \
@@ -1497,7 +1544,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
             return ESCAT_OK;
         }
     }
-    if (sell && sell->part_list) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
+    if (sell && (sell->part_list || sell->orders)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
     if (sell && sell->col32 && T > 0) {
         // packed multi-launch path: float4-per-node intermediate vectors
         if (!sell->val || !sell->perm || !sell->slice_doff) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");

@@ -36,20 +36,25 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else 0) if t is not None else ctypes.c_void_p(0)
 
 
-def chain_lds_bytes(max_part_rows: int, C: int, F: int, bsr3: bool, backward: bool = False) -> int:
+def chain_lds_bytes(max_part_rows: int, C: int, F: int, bsr3: bool, backward: bool = False, orders: int = 0) -> int:
     """LDS a register-resident chain workgroup needs at least: two ping-pong vectors of two copies each, the output
     slab, and (forward) the staged input.  (Backward adds a second slab when it fits -- decided in the library.)"""
     from .operators import sell_pad_rows
     CP = 4 if bsr3 else (1 if C == 1 else 2 if C == 2 else 4 if C <= 4 else 8)
     cw = 3 if bsr3 else C
-    slab = (max_part_rows * cw * F + 3) & ~3
+    slab = (max_part_rows * cw * (F + (1 if orders and not backward else 0)) + 3) & ~3
     stage = 0 if backward else (max_part_rows * cw + 3) & ~3
     return (2 * 2 * sell_pad_rows(max_part_rows) * CP + slab + stage) * 4
 
 
-def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool) -> torch.Tensor:
+class NoFusedOrders(Exception):
+    """the launch cannot fuse the orders epilogue (not on the register-resident path): the caller uses two kernels"""
+
+
+def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool, orders: int = 0) -> torch.Tensor:
     """one call into the C ABI for <= MAX_C channels.  inp: fwd (n,C) / bwd (n,C,F); returns fwd (n,C,F) / bwd (n,C).
-    op: a ScatterOperator, or an OperatorBatch (parts of a stored operator, walked in place)."""
+    op: a ScatterOperator, or an OperatorBatch (parts of a stored operator, walked in place).
+    orders (forward): 1 / 2 = return (n, C, Wtot) = [x | bank (| pair products)] from the chain's own epilogue."""
     lib = _lib.load()
     dev = inp.device
     view = op if isinstance(op, OperatorBatch) else None
@@ -60,8 +65,9 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
     use_bsr = C == 1 and op.has_bsr3
     form = (op.bsr3_t() if backward else op.bsr3()) if use_bsr else (op.csr_t() if backward else op.csr())
     rows_per = 3 if use_bsr else 1
-    out = torch.empty((n, C) if backward else (n, C, F), dtype=torch.float32, device=dev)
-    lds = chain_lds_bytes(form.max_part_rows, C, F, use_bsr, backward)
+    Wout = F if orders == 0 else 1 + F + (F * (F - 1) // 2 if orders == 2 else 0)
+    out = torch.empty((n, C) if backward else (n, C, Wout), dtype=torch.float32, device=dev)
+    lds = chain_lds_bytes(form.max_part_rows, C, F, use_bsr, backward, orders)
     path = os.environ.get("ESCAT_CHAIN_PATH", "")
     fused = form.n_parts > 0 and lds <= LDS_BUDGET and not path.startswith("multi")
     ws = None
@@ -71,6 +77,8 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
     sell = form.sell() if fused else None
     if sell is not None and (form.max_part_rows * rows_per * C > 0xffff or path == "stream"):
         sell = None
+    if orders and sell is None:
+        raise NoFusedOrders()
     if view is not None and sell is None:
         raise NotImplementedError("escat: an OperatorBatch needs the register-resident path (parts of <= 512 rows that fit LDS)")
     if view is not None and n == 0:
@@ -82,7 +90,7 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
             plist, prow0 = view.lists_for(form)
             pl, pr, nl = plist.data_ptr(), prow0.data_ptr(), int(plist.numel())
         sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(),
-                                     sell.dmax, sell.n_slices, sell.slices_per_part, 0, 0, 0, 0, pl, pr, nl)
+                                     sell.dmax, sell.n_slices, sell.slices_per_part, 0, 0, 0, 0, pl, pr, nl, orders)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
@@ -90,7 +98,7 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         # random node order where the x gather dominates), so the default multi-launch path stays unpacked.
         sg = form.sell_global()
         sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, 0, 0, sg.n_slices, 0, 0,
-                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0)
+                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)

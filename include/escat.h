@@ -105,6 +105,12 @@ typedef struct {
     const int32_t  *part_list;
     const int32_t  *part_row0;
     int32_t         n_list;
+    /* optional, forward entry points on the register-resident path only: fuse the orders 0/1/2 of
+     * ESCGNNModular._scatter (models/escgnn_modular.py:333-341) into the chain's epilogue.  0: OUT = the bank (n, C, F);
+     * 1: OUT (n, C, 1+F) = [x | bank]; 2: OUT (n, C, 1+F+F(F-1)/2) = [x | bank | bank_i*bank_j, i<j in triu order]
+     * -- what escat_scatter_orders_f32 would make of the bank, without the bank's round trip through HBM.
+     * Must be 0 for the backward entry points. */
+    int32_t         orders;
 } escat_sell;
 
 /* Pack-time planning for escat_sell: for every entry e among the first dmax of its row, the slot (column of its

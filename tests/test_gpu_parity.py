@@ -452,6 +452,52 @@ def test_locality_reordering_is_transparent(monkeypatch):
     _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=2e-5)
 
 
+def test_scatter_fused_and_two_kernel_forms_agree(monkeypatch):
+    """_scatter through the fused launch (orders epilogue inside the chain kernel) and through bank + orders kernels
+    (forced by ESCAT_CHAIN_PATH=stream, and taken by itself for a graph that does not fit LDS): same values, same grads."""
+    from esc_gnn_amd import scatter, ScatterOperator, synthetic
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(20, 300, 8, seed=31)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    g = torch.Generator().manual_seed(2)
+    xs = torch.randn(b["N"], 3, generator=g).to(dev); xv = t(b["pos"])
+    res = {}
+    for path in ("reg", "stream"):
+        monkeypatch.setenv("ESCAT_CHAIN_PATH", path)
+        for abl in (False, True):
+            for kw in ({"diffusion_kwargs": dict(scales_type="dyadic", J=3)},
+                       {"diffusion_kwargs": dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6]))}):
+                a = xs.clone().requires_grad_(True); v = xv.clone().requires_grad_(True)
+                Ws = scatter(track="scalar", x0=a, P_or_Q=opP, kwargs=kw, ablate_second_order_wavelets=abl)
+                Wv = scatter(track="vector", x0=v, P_or_Q=opQ, kwargs=kw, ablate_second_order_wavelets=abl)
+                Gs = torch.randn(Ws.shape, generator=torch.Generator().manual_seed(7)).to(dev)
+                Gv = torch.randn(Wv.shape, generator=torch.Generator().manual_seed(8)).to(dev)
+                torch.autograd.backward([Ws, Wv], [Gs, Gv])
+                key = (abl, str(kw["diffusion_kwargs"].get("scales_type")))
+                if path == "reg":
+                    res[key] = (Ws.detach(), Wv.detach(), a.grad, v.grad)
+                    # without a gradient the same call is ONE fused launch (orders written by the chain's epilogue)
+                    with torch.no_grad():
+                        Fs = scatter(track="scalar", x0=xs, P_or_Q=opP, kwargs=kw, ablate_second_order_wavelets=abl)
+                        Fv = scatter(track="vector", x0=xv, P_or_Q=opQ, kwargs=kw, ablate_second_order_wavelets=abl)
+                    assert torch.equal(Fs[..., 0], xs) and Fs.shape == Ws.shape and Fv.shape == Wv.shape
+                    assert (Fs - Ws).abs().max() <= 1e-6 * Ws.abs().max() and (Fv - Wv).abs().max() <= 1e-6 * Wv.abs().max()
+                else:
+                    for got, want in zip((Ws.detach(), Wv.detach(), a.grad, v.grad), res[key]):
+                        assert got.shape == want.shape
+                        assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+    monkeypatch.delenv("ESCAT_CHAIN_PATH")
+    big = synthetic.single_cloud(3000, 6, workers=1)
+    opB = ScatterOperator.from_csr(t(big["rowptr"]), t(big["col"]), t(big["pval"]), big["N"])
+    xb = t(big["pos"]).clone().requires_grad_(True)
+    Wb = scatter(track="scalar", x0=xb, P_or_Q=opB, kwargs={"diffusion_kwargs": dict(J=2)})
+    assert Wb.shape == (3000, 3, 1 + 4 + 6) and torch.equal(Wb[..., 0], xb.detach())
+    assert torch.allclose(Wb[..., 5], Wb[..., 1] * Wb[..., 2])
+    Wb.sum().backward(); assert torch.isfinite(xb.grad).all()
+
+
 def test_register_path_long_rows_and_small_parts():
     """rows longer than the register capacity (DMAX) take the streamed tail; parts of many tiny graphs."""
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
