@@ -200,7 +200,7 @@ def main():
         bytes_p = alg_bytes_scalar(N, nnz, C, T, F)
         achieved = bytes_q / (per["Q_fwd"] * 1e-3) / 1e9
         comp_q = compulsory_bytes_vector(N, nnz, F)
-        traffic = measured_traffic(args, "k_chain_sell<OpBsr3", ", false>")
+        traffic = measured_traffic(args, "k_chain_sell<OpBsr3", ", false, false>")
         out = {
             "metric": "graphs/sec for P+Q scattering fwd+bwd (J=4)",
             "value": args.graphs * world * args.steps / dt,
@@ -213,7 +213,7 @@ def main():
                                    f"P (CSR, C=3) + Q (BSR-3) dyadic J={args.J} + lowpass, fwd+bwd",
                        "graphs_per_gpu": args.graphs, "nodes_per_graph": args.nodes, "k": args.k, "J": args.J,
                        "N": N, "nnz_P": nnz, "T": T, "F": F, "parallelism": f"dp{world} (graph shards, no data-path collective)"},
-            "roofline": {"bound": "hbm", "kernel": "k_chain_sell<OpBsr3<..>, 512, false> (Q chain forward)",
+            "roofline": {"bound": "hbm", "kernel": "k_chain_sell<OpBsr3<..>, 512, false, false> (Q chain forward)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_q, "ms_per_launch": per["Q_fwd"],

@@ -833,15 +833,15 @@ __device__ __forceinline__ void chain_epilogue_orders(const float *slab, float *
 // (a CU pulls ~12-24 GB/s from HBM); the metadata hops, the input latency and the output stores are hidden.
 //   LDS: xa | xb (two copies each) | slab | inb   -- inb = staged x (fwd) or the second slab (bwd, `early`);
 //   bwd without room for two slabs (`early` = 0) copies the next input in after the last step instead.
-template <class Op, int NT, bool BWD>
-__global__ void __launch_bounds__(NT, Op::MINW)
+template <class Op, int NT, bool BWD, bool ORD>     // ORD: forward with the orders epilogue (a separate instantiation:
+__global__ void __launch_bounds__(NT, Op::MINW)      // compiled into the plain kernel, its code costs the step loop registers)
 k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev sd, const float *__restrict__ IN,
              float *__restrict__ RES, int T, EvTable tab, int F, int n_parts, int max_rows, int early)
 {
     constexpr int C = Op::C, CP = Op::CP;
     extern __shared__ __align__(16) float smem[];
     const int nv = 2 * sell_padR(max_rows) * CP;                 // two copies per vector, a multiple of 32 floats
-    const int so = (!BWD && sd.orders) ? 1 : 0, Fs = F + so;    // fused orders: slab rows are [x | bank]
+    const int so = ORD ? 1 : 0, Fs = F + so;                    // fused orders: slab rows are [x | bank]
     const int slab_sz = (max_rows * C * Fs + 3) & ~3;
     float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
     float *inb = (BWD && !early) ? slab : slab + slab_sz;
@@ -880,7 +880,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         STAMP(li, 1);
         // ... and store the previous part's result underneath the stream
         if (prev_rows >= 0) {
-            if (!BWD && sd.orders) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
+            if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
             else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
         }
         STAMP(li, 2);
@@ -955,7 +955,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         li = liN; part = partN; row0 = row0N; rt = rtN; te0 = te0N; sw = swN;
         if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
     }
-    if (!BWD && sd.orders) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
+    if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
     else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
 }
 
@@ -1331,16 +1331,15 @@ static size_t sell_lds_bytes(int C, int CP, int max_rows, int F, bool bwd, int w
     return base;
 }
 
-template <class Op, int NT, bool BWD>
-static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_rows, const SellDev &sd, const float *IN,
-                         float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+template <class Op, int NT, bool BWD, bool ORD>
+static int launch_sell_k2(const int *ci, const float *v, int n_parts, int max_rows, const SellDev &sd, const float *IN,
+                          float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
-    if (sd.nsl * 64 != NT) return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d does not match parts of <= %d rows", sd.nsl, max_rows);
     int early = 0;
     const int want = Op::MINW == 1 ? 1 : (NT == 512 ? 2 : 4);
     const size_t lds = sell_lds_bytes(Op::C, Op::CP, max_rows, F, BWD, want, &early, sd.orders);
     if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "register-resident chain needs %zu B of LDS", lds);
-    auto kern = k_chain_sell<Op, NT, BWD>;
+    auto kern = k_chain_sell<Op, NT, BWD, ORD>;
     int rc = set_lds(kern, lds); if (rc) return rc;
     // resident workgroups per CU: cached per instantiation, LDS size and device (thread_local: no locking needed)
     static thread_local size_t cached_lds = (size_t)-1; static thread_local int cached_per_cu = 0, cached_dev = -1;
@@ -1355,6 +1354,15 @@ static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_row
     const int grid = (int)(n_parts < resident ? n_parts : resident);           // persistent: one wave of workgroups
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ci, v, sd, IN, RES, T, tab, F, n_parts, max_rows, early);
     return ESCAT_OK;
+}
+
+template <class Op, int NT, bool BWD>
+static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_rows, const SellDev &sd, const float *IN,
+                         float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    if (sd.nsl * 64 != NT) return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d does not match parts of <= %d rows", sd.nsl, max_rows);
+    if (!BWD && sd.orders) return launch_sell_k2<Op, NT, false, true>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+    return launch_sell_k2<Op, NT, BWD, false>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
 }
 
 template <int DMAX, bool BWD>
@@ -1392,10 +1400,11 @@ static int launch_csr_sell_c(int max_rows, const int *ci, const float *v, int n_
     switch (sd.dmax) {
         case 8:  return launch_csr_sell_d<C, 8, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
         case 16: return launch_csr_sell_d<C, 16, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        case 20: return launch_csr_sell_d<C, 20, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
         case 24: return launch_csr_sell_d<C, 24, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
         case 32: return launch_csr_sell_d<C, 32, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
     }
-    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: CSR packs must use 8, 16, 24 or 32", sd.dmax);
+    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: CSR packs must use 8, 16, 20, 24 or 32", sd.dmax);
 }
 template <bool BWD>
 static int launch_csr_sell(int C, int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd,

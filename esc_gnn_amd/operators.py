@@ -124,7 +124,7 @@ def locality_order(rowptr: torch.Tensor, col: torch.Tensor, n: int, max_componen
 
 
 SELL_MAX_PART_ROWS = 512
-_SELL_DMAX = {1: (8, 16, 24, 32), 9: (8, 12, 16, 20, 22)}     # register capacities the kernels are instantiated for
+_SELL_DMAX = {1: (8, 16, 20, 24, 32), 9: (8, 12, 16, 20, 22)}     # register capacities the kernels are instantiated for
 # rows longer than the capacity stream their tail from L2 every step (slow for their whole workgroup), but the largest
 # BSR-3 capacity leaves the kernel short of registers: accept a capacity that leaves at most this fraction of rows a tail
 _SELL_TAIL_ROWS = 5e-5

@@ -80,7 +80,7 @@ typedef struct { int32_t step, slot, sign, chan; } escat_event;
  *   lane_meta[(s*64 + lane)*3 + 2] = slice word: lanes 0..4 hold doff_s, poff_s, w_s, first row of the part,
  *                                    rows of the part (one 12-byte load per lane starts a part)
  * val and lc end with one padding slot / pair (the kernels read it for empty slices).
- * dmax: 8/16/24/32 (CSR), 8/12/16/20/22 (BSR-3).
+ * dmax: 8/16/20/24/32 (CSR), 8/12/16/20/22 (BSR-3).
  * esc_gnn_amd/operators.py builds it (torch index ops + escat_sell_plan_slots, once per operator). */
 typedef struct {
     const float    *val;
