@@ -22,7 +22,7 @@
 
 __global__ void __launch_bounds__(POOL_NT)
 k_pool_fwd(const float *__restrict__ vals, const int *__restrict__ seg_ptr, int64_t n_nodes, int W, int stats, int n_levels,
-           const int *__restrict__ k_table, int table_ld, float *__restrict__ out, int *__restrict__ arg)
+           const int *__restrict__ k_table, int table_ld, float *__restrict__ out, unsigned char *__restrict__ arg)
 {
     extern __shared__ float lds[];                 // [POOL_MAX_DEG][POOL_NT] values, then the same of positions (bytes)
     float *sv = lds;
@@ -45,19 +45,19 @@ k_pool_fwd(const float *__restrict__ vals, const int *__restrict__ seg_ptr, int6
             sv[j * POOL_NT + tid] = x; sp[j * POOL_NT + tid] = (unsigned char)i;
         }
         float *o = out + n * (int64_t)m * W + w;
-        int *a = arg ? arg + n * (int64_t)na * W + w : nullptr;
+        unsigned char *a = arg ? arg + n * (int64_t)na * W + w : nullptr;
         int s = 0, sa = 0;
         const float mean = cnt > 0 ? sum / (float)cnt : 0.f;
         if (stats & ST_MEAN) { o[(int64_t)s * W] = mean; ++s; }
         if (stats & ST_MAX) {                        // first of equal maxima in edge order
             float v = 0.f; int p = 0;
             if (cnt > 0) { int q = cnt - 1; v = sv[q * POOL_NT + tid]; while (q > 0 && sv[(q - 1) * POOL_NT + tid] == v) --q; p = sp[q * POOL_NT + tid]; }
-            o[(int64_t)s * W] = v; ++s; if (a) { a[(int64_t)sa * W] = p; } ++sa;
+            o[(int64_t)s * W] = v; ++s; if (a) { a[(int64_t)sa * W] = (unsigned char)p; } ++sa;
         }
         if (stats & ST_MIN) {
             float v = 0.f; int p = 0;
             if (cnt > 0) { v = sv[tid]; p = sp[tid]; }
-            o[(int64_t)s * W] = v; ++s; if (a) { a[(int64_t)sa * W] = p; } ++sa;
+            o[(int64_t)s * W] = v; ++s; if (a) { a[(int64_t)sa * W] = (unsigned char)p; } ++sa;
         }
         if (stats & ST_VAR) {
             float v = 0.f;
@@ -67,7 +67,7 @@ k_pool_fwd(const float *__restrict__ vals, const int *__restrict__ seg_ptr, int6
         for (int l = 0; l < n_levels; ++l) {
             float v = 0.f; int p = 0;
             if (cnt > 0) { const int k = k_table[l * table_ld + cnt]; v = sv[k * POOL_NT + tid]; p = sp[k * POOL_NT + tid]; }
-            o[(int64_t)s * W] = v; ++s; if (a) { a[(int64_t)sa * W] = p; } ++sa;
+            o[(int64_t)s * W] = v; ++s; if (a) { a[(int64_t)sa * W] = (unsigned char)p; } ++sa;
         }
     }
 }
@@ -75,7 +75,7 @@ k_pool_fwd(const float *__restrict__ vals, const int *__restrict__ seg_ptr, int6
 // gradient w.r.t. the per-edge values: every (node, column) owns its segment's column, so no atomics
 __global__ void __launch_bounds__(POOL_NT)
 k_pool_bwd(const float *__restrict__ vals, const int *__restrict__ seg_ptr, int64_t n_nodes, int W, int stats, int n_levels,
-           const float *__restrict__ gout, const int *__restrict__ arg, float *__restrict__ gvals)
+           const float *__restrict__ gout, const unsigned char *__restrict__ arg, float *__restrict__ gvals)
 {
     const int m = ((stats & ST_MEAN) ? 1 : 0) + ((stats & ST_MAX) ? 1 : 0) + ((stats & ST_MIN) ? 1 : 0) + ((stats & ST_VAR) ? 1 : 0) + n_levels;
     const int na = ((stats & ST_MAX) ? 1 : 0) + ((stats & ST_MIN) ? 1 : 0) + n_levels;
@@ -85,7 +85,7 @@ k_pool_bwd(const float *__restrict__ vals, const int *__restrict__ seg_ptr, int6
         const int e0 = seg_ptr[n], cnt = seg_ptr[n + 1] - e0;
         if (cnt <= 0) continue;
         const float *go = gout + n * (int64_t)m * W + w;
-        const int *a = arg + n * (int64_t)na * W + w;
+        const unsigned char *a = arg + n * (int64_t)na * W + w;
         int s = 0;
         float gmean = 0.f, gvar = 0.f;
         if (stats & ST_MEAN) { gmean = go[(int64_t)s * W]; ++s; }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void gather_cosines(const float *__restrict__ v, cons
 template <int D>
 __global__ void __launch_bounds__(POOL_NT)
 k_vinv_fwd(const float *__restrict__ v, const int *__restrict__ src, const int *__restrict__ seg_ptr, int64_t n_nodes, int W,
-           int stats, int n_levels, const int *__restrict__ k_table, int table_ld, float *__restrict__ out, int *__restrict__ arg,
+           int stats, int n_levels, const int *__restrict__ k_table, int table_ld, float *__restrict__ out, unsigned char *__restrict__ arg,
            int cap)
 {
     extern __shared__ float lds[];                 // [cap][POOL_NT] values, then as many position bytes
@@ -187,7 +187,7 @@ k_vinv_fwd(const float *__restrict__ v, const int *__restrict__ src, const int *
             sv[j * POOL_NT + tid] = x; sp[j * POOL_NT + tid] = (unsigned char)i;
         }
         float *o = out + n * (int64_t)(1 + m) * W + w;
-        int *ar = arg ? arg + n * (int64_t)na * W + w : nullptr;
+        unsigned char *ar = arg ? arg + n * (int64_t)na * W + w : nullptr;
         o[0] = nrm;
         int s = 1, sa = 0;
         const float mean = cnt > 0 ? sum / (float)cnt : 0.f;
@@ -195,12 +195,12 @@ k_vinv_fwd(const float *__restrict__ v, const int *__restrict__ src, const int *
         if (stats & ST_MAX) {
             float x = 0.f; int p = 0;
             if (cnt > 0) { int q = cnt - 1; x = sv[q * POOL_NT + tid]; while (q > 0 && sv[(q - 1) * POOL_NT + tid] == x) --q; p = sp[q * POOL_NT + tid]; }
-            o[(int64_t)s * W] = x; ++s; if (ar) { ar[(int64_t)sa * W] = p; } ++sa;
+            o[(int64_t)s * W] = x; ++s; if (ar) { ar[(int64_t)sa * W] = (unsigned char)p; } ++sa;
         }
         if (stats & ST_MIN) {
             float x = 0.f; int p = 0;
             if (cnt > 0) { x = sv[tid]; p = sp[tid]; }
-            o[(int64_t)s * W] = x; ++s; if (ar) { ar[(int64_t)sa * W] = p; } ++sa;
+            o[(int64_t)s * W] = x; ++s; if (ar) { ar[(int64_t)sa * W] = (unsigned char)p; } ++sa;
         }
         if (stats & ST_VAR) {
             float x = 0.f;
@@ -210,7 +210,7 @@ k_vinv_fwd(const float *__restrict__ v, const int *__restrict__ src, const int *
         for (int l = 0; l < n_levels; ++l) {
             float x = 0.f; int p = 0;
             if (cnt > 0) { const int k = k_table[l * table_ld + cnt]; x = sv[k * POOL_NT + tid]; p = sp[k * POOL_NT + tid]; }
-            o[(int64_t)s * W] = x; ++s; if (ar) { ar[(int64_t)sa * W] = p; } ++sa;
+            o[(int64_t)s * W] = x; ++s; if (ar) { ar[(int64_t)sa * W] = (unsigned char)p; } ++sa;
         }
     }
 }
@@ -222,7 +222,7 @@ k_vinv_fwd(const float *__restrict__ v, const int *__restrict__ src, const int *
 template <int D, bool TWO_PASS>
 __global__ void __launch_bounds__(POOL_NT)
 k_vinv_bwd(const float *__restrict__ v, const int *__restrict__ src, const int *__restrict__ seg_ptr, int64_t n_nodes, int W,
-           int stats, int n_levels, const float *__restrict__ gout, const int *__restrict__ arg, float *__restrict__ dv,
+           int stats, int n_levels, const float *__restrict__ gout, const unsigned char *__restrict__ arg, float *__restrict__ dv,
            float *__restrict__ gedge)
 {
     extern __shared__ float lds[];
@@ -247,7 +247,7 @@ k_vinv_bwd(const float *__restrict__ v, const int *__restrict__ src, const int *
         }
         const int e0 = seg_ptr[n], cnt = seg_ptr[n + 1] - e0;
         if (cnt > 0) {
-            const int *ar = arg + n * (int64_t)na * W + w;
+            const unsigned char *ar = arg + n * (int64_t)na * W + w;
             float sum = 0.f, sq = 0.f;
             gather_cosines<D>(v, src, e0, cnt, W, w, a, nac, sc, tid, sum, sq);
             int s = 1;
@@ -364,7 +364,7 @@ static int pool_grid(int64_t work)
 }
 
 extern "C" int escat_neighbor_pool_f32(const float *vals, const int32_t *seg_ptr, int64_t n_nodes, int W, int max_deg,
-                                       int stats, int n_levels, const int32_t *k_table, float *out, int32_t *arg, void *stream)
+                                       int stats, int n_levels, const int32_t *k_table, float *out, uint8_t *arg, void *stream)
 {
     if (!vals || !seg_ptr || !out) return escat_fail(ESCAT_EINVAL, "NULL pointer");
     if (W < 1 || n_levels < 0 || (stats & ~15)) return escat_fail(ESCAT_EINVAL, "bad W / stats / n_levels");
@@ -383,7 +383,7 @@ extern "C" int escat_neighbor_pool_f32(const float *vals, const int32_t *seg_ptr
 }
 
 extern "C" int escat_neighbor_pool_bwd_f32(const float *vals, const int32_t *seg_ptr, int64_t n_nodes, int W, int stats,
-                                           int n_levels, const float *gout, const int32_t *arg, float *gvals, void *stream)
+                                           int n_levels, const float *gout, const uint8_t *arg, float *gvals, void *stream)
 {
     if (!vals || !seg_ptr || !gout || !gvals) return escat_fail(ESCAT_EINVAL, "NULL pointer");
     const int na = ((stats & ST_MAX) ? 1 : 0) + ((stats & ST_MIN) ? 1 : 0) + n_levels;
@@ -398,7 +398,7 @@ extern "C" int escat_neighbor_pool_bwd_f32(const float *vals, const int32_t *seg
 }
 
 extern "C" int escat_vector_invariants_f32(const float *v, const int32_t *src, const int32_t *seg_ptr, int64_t n_nodes, int W, int d,
-                                           int max_deg, int stats, int n_levels, const int32_t *k_table, float *out, int32_t *arg,
+                                           int max_deg, int stats, int n_levels, const int32_t *k_table, float *out, uint8_t *arg,
                                            void *stream)
 {
     if (!v || !seg_ptr || !out || (!src && max_deg > 0)) return escat_fail(ESCAT_EINVAL, "NULL pointer");
@@ -423,7 +423,7 @@ extern "C" int escat_vector_invariants_f32(const float *v, const int32_t *src, c
 }
 
 extern "C" int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const int32_t *seg_ptr, int64_t n_nodes, int W,
-                                               int d, int max_deg, int stats, int n_levels, const float *gout, const int32_t *arg, float *dv,
+                                               int d, int max_deg, int stats, int n_levels, const float *gout, const uint8_t *arg, float *dv,
                                                const int32_t *dst, const int32_t *out_ptr, const int32_t *out_edge, float *gedge,
                                                void *stream)
 {

@@ -78,7 +78,7 @@ class _NeighborPool(torch.autograd.Function):
         m = bin(stats).count("1") + n_levels
         na = (1 if stats & 2 else 0) + (1 if stats & 4 else 0) + n_levels
         out = torch.empty(n_nodes, m * W, dtype=torch.float32, device=vals.device)
-        arg = torch.empty(n_nodes, max(na, 1) * W, dtype=torch.int32, device=vals.device)
+        arg = torch.empty(n_nodes, max(na, 1) * W, dtype=torch.uint8, device=vals.device)
         with torch.cuda.device(vals.device):
             rc = lib.escat_neighbor_pool_f32(_ptr(vals), _ptr(seg_ptr), n_nodes, W, max_deg, stats, n_levels, _ptr(ktab),
                                              _ptr(out), _ptr(arg), _stream(vals.device))
@@ -112,7 +112,7 @@ class _VectorInvariants(torch.autograd.Function):
         m = bin(stats).count("1") + n_levels
         na = (1 if stats & 2 else 0) + (1 if stats & 4 else 0) + n_levels
         out = torch.empty(N, (1 + m) * W, dtype=torch.float32, device=v.device)
-        arg = torch.empty(N, max(na, 1) * W, dtype=torch.int32, device=v.device)
+        arg = torch.empty(N, max(na, 1) * W, dtype=torch.uint8, device=v.device)
         with torch.cuda.device(v.device):
             rc = lib.escat_vector_invariants_f32(_ptr(v), _ptr(eg.src_s), _ptr(eg.seg_ptr), N, W, d, eg.max_deg, stats, n_levels,
                                                  _ptr(ktab), _ptr(out), _ptr(arg), _stream(v.device))

@@ -246,13 +246,13 @@ int escat_build_Q_bsr3(const int32_t *rowptr, const int32_t *col, const float *p
  * E[x^2]-E[x]^2 clamped at 0 (3), then n_levels lower quantiles: the k-th smallest with k = k_table[l*65 + deg]
  * (the caller tabulates floor((deg-1)*p_l) exactly as the reference's Python does, :493-496).  Nodes without
  * incoming edges get 0 everywhere.  out (n_nodes, m*W) = the reference's torch.cat of (N, W) blocks in the order
- * mean, max, min, var, levels; arg (n_nodes, na*W), na = [max] + [min] + n_levels: position inside the node's
+ * mean, max, min, var, levels; arg (n_nodes, na*W) bytes, na = [max] + [min] + n_levels: position inside the node's
  * segment of the selected edge (first in edge order among equals), for the backward pass; may be NULL. */
 int escat_neighbor_pool_f32(const float *vals, const int32_t *seg_ptr, int64_t n_nodes, int W, int max_deg,
-                            int stats, int n_levels, const int32_t *k_table, float *out, int32_t *arg, void *stream);
+                            int stats, int n_levels, const int32_t *k_table, float *out, uint8_t *arg, void *stream);
 /* gradient w.r.t. vals: gout (n_nodes, m*W) -> gvals (E, W); every element of gvals is written. */
 int escat_neighbor_pool_bwd_f32(const float *vals, const int32_t *seg_ptr, int64_t n_nodes, int W, int stats,
-                                int n_levels, const float *gout, const int32_t *arg, float *gvals, void *stream);
+                                int n_levels, const float *gout, const uint8_t *arg, float *gvals, void *stream);
 
 /* ---- the whole of _get_vector_invariants in one kernel per direction (models/escgnn_modular.py:414-504):
  * v (n_nodes, W, d) coefficients (d = 2 or 3); in-edges of node n = src[seg_ptr[n] .. seg_ptr[n+1]) (edge_index
@@ -260,7 +260,7 @@ int escat_neighbor_pool_bwd_f32(const float *vals, const int32_t *seg_ptr, int64
  * cos(v[n], v[src]) with both norms clamped at 1e-8 (:425-429).  out (n_nodes, (1+m)*W) = [norm | mean | max | min |
  * var | levels]; arg as above.  Nothing of size (E, W) is materialised. */
 int escat_vector_invariants_f32(const float *v, const int32_t *src, const int32_t *seg_ptr, int64_t n_nodes, int W, int d,
-                                int max_deg, int stats, int n_levels, const int32_t *k_table, float *out, int32_t *arg,
+                                int max_deg, int stats, int n_levels, const int32_t *k_table, float *out, uint8_t *arg,
                                 void *stream);
 /* gradient w.r.t. v.  Two forms:
  *  - gedge == NULL: one kernel, float atomics; dv (n_nodes, W, d) must be ZERO on entry;
@@ -268,7 +268,7 @@ int escat_vector_invariants_f32(const float *v, const int32_t *src, const int32_
  *    grouped by source: dst[e] = destination of edge e (in the destination-grouped order the forward used),
  *    out_edge[out_ptr[n] .. out_ptr[n+1]) = the edges e whose source is node n. */
 int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const int32_t *seg_ptr, int64_t n_nodes, int W, int d,
-                                    int max_deg, int stats, int n_levels, const float *gout, const int32_t *arg, float *dv,
+                                    int max_deg, int stats, int n_levels, const float *gout, const uint8_t *arg, float *dv,
                                     const int32_t *dst, const int32_t *out_ptr, const int32_t *out_edge, float *gedge,
                                     void *stream);
 
