@@ -56,8 +56,8 @@ static int build_table(const escat_event *ev, int n_ev, int T, int F, int C, EvT
 {
     if (n_ev < 0 || n_ev > ESCAT_MAX_EVENTS) return fail(ESCAT_ERANGE, "n_events=%d exceeds ESCAT_MAX_EVENTS", n_ev);
     if (n_ev > 0 && !ev) return fail(ESCAT_EINVAL, "events is NULL");
-    if (F < 1 || F > 64) return fail(ESCAT_ERANGE, "F=%d out of range [1,64]", F);
-    static thread_local unsigned char seen[64 * ESCAT_MAX_CHANNELS];
+    if (F < 1 || F > ESCAT_MAX_SLOTS) return fail(ESCAT_ERANGE, "F=%d out of range [1,%d]", F, ESCAT_MAX_SLOTS);
+    static thread_local unsigned char seen[ESCAT_MAX_SLOTS * ESCAT_MAX_CHANNELS];
     memset(seen, 0, sizeof(seen));
     tab->n = n_ev;
     for (int k = 0; k < n_ev; ++k) {

@@ -55,6 +55,7 @@ extern "C" {
 
 #define ESCAT_MAX_EVENTS   160
 #define ESCAT_MAX_CHANNELS 8    /* per launch; the host side chunks wider X */
+#define ESCAT_MAX_SLOTS    160  /* F: output slots of a chain (the all-powers plan of infogain uses T+1) */
 
 typedef struct { int32_t step, slot, sign, chan; } escat_event;
 
@@ -271,6 +272,24 @@ int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const in
                                     int max_deg, int stats, int n_levels, const float *gout, const uint8_t *arg, float *dv,
                                     const int32_t *dst, const int32_t *out_ptr, const int32_t *out_edge, float *gedge,
                                     void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Infogain scale selection (models/infogain.py:172-664): per-graph divergence of every diffusion power against the
+ * last one.  Replaces the Python loops of get_divergence_by_channel (models/infogain.py:810-900) + normalize_channels
+ * (:780-807) + get_floor (:760-777) + nn_utilities.norm_tensor_to_prob_mass / minmax_scale_tensor /
+ * get_mid_btw_min_and_2nd_low_vector_vals (models/nn_utilities.py:76-245) over graphs x channels x steps.
+ *   W          (N, C, F) fp32: the powers P^t x, t = 0..F-1, step fastest -- what escat_chain_*_f32 writes for the
+ *              all-powers event table {step t -> slot t, +1} (the stack of :397-404 without the (T+1, N, C) copy)
+ *   graph_ptr  (n_graphs + 1) row offsets of the graphs in W (rows = d * nodes for a flattened vector feature)
+ *   start      first step compared (Ptx_i_start, :317); steps start .. F-2 are compared with step F-1
+ *   metric     0 = KL(q_T || p_t) = sum q (log q - log(p + 1e-12)) (:857-863), 1 = L1 (:866)
+ *   fixed_floor / floor_val   1: above_zero_floor = floor_val (divergence_metric_kwargs['above_zero_floor']);
+ *              0: midpoint of the lowest and second-lowest distinct value of each column (nn_utilities.py:202-245)
+ *   out        (n_graphs, F-1-start, C) fp32, summed over the graph's rows (:891-898)
+ *   status     (n_graphs) int32, set to 1 where a column cannot be normalised (no variance / zero floor: the
+ *              reference fails with a TypeError there); the corresponding out entries are NaN */
+int escat_infogain_divergence_f32(const float *W, const int32_t *graph_ptr, int64_t n_graphs, int C, int F, int start,
+                                  int metric, int fixed_floor, float floor_val, float *out, int32_t *status, void *stream);
 
 /* host utility (no GPU): Jenkins lookup3 "hashlittle", the checksum of HDF5 version-2 object headers
  * (esc_gnn_amd/hdf5_min.py, the writer of the reference's operator layout). */

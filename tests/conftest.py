@@ -32,3 +32,8 @@ def sg():
 @pytest.fixture(scope="session")
 def bg():
     return np.load(os.path.join(GOLDEN, "builder_goldens.npz"))
+
+
+@pytest.fixture(scope="session")
+def ig():
+    return np.load(os.path.join(GOLDEN, "infogain_goldens.npz"))
