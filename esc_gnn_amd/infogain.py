@@ -55,9 +55,12 @@ def diffusion_powers(x: torch.Tensor, P_sparse, T: int) -> torch.Tensor:
 
 
 def divergence_by_graph(Ptxs: torch.Tensor, graph_ptr: torch.Tensor, Ptx_i_start: int = 2, divergence_metric: str = "kl",
-                        above_zero_floor: Optional[float] = None, check: bool = True) -> torch.Tensor:
+                        above_zero_floor: Optional[float] = None, check: bool = True,
+                        max_graph_rows: Optional[int] = None) -> torch.Tensor:
     """get_divergence_by_channel (models/infogain.py:810-900) for every graph of a batch at once.
-    Ptxs (N, C, T+1) from diffusion_powers; graph_ptr (B+1) row offsets -> (B, T - Ptx_i_start, C)."""
+    Ptxs (N, C, T+1) from diffusion_powers; graph_ptr (B+1) row offsets -> (B, T - Ptx_i_start, C).
+    max_graph_rows: the largest graph's rows if already known (saves one device->host read); 0 forces the
+    three-pass kernel."""
     metric = divergence_metric.lower()
     if metric in DIVERGENCE_TYPES_MAP["ot"]:
         raise NotImplementedError("escat: optimal-transport divergences (POT library, per-graph shortest-path cost "
@@ -71,12 +74,16 @@ def divergence_by_graph(Ptxs: torch.Tensor, graph_ptr: torch.Tensor, Ptx_i_start
     gp = graph_ptr.to(device=Ptxs.device, dtype=torch.int32).contiguous()
     out = torch.empty(B, F - 1 - Ptx_i_start, C, dtype=torch.float32, device=Ptxs.device)
     status = torch.empty(max(B, 1), dtype=torch.int32, device=Ptxs.device)
+    if max_graph_rows is None:
+        max_graph_rows = int((gp[1:] - gp[:-1]).max()) if B else 0
+    if B and (int(gp[-1]) > N or max_graph_rows < 0):
+        raise ValueError("escat: graph_ptr runs past the rows of Ptxs")
     with torch.cuda.device(Ptxs.device):
         rc = lib.escat_infogain_divergence_f32(_ptr(Wc), _ptr(gp), B, C, F, int(Ptx_i_start),
                                                0 if metric in DIVERGENCE_TYPES_MAP["kl"] else 1,
                                                0 if above_zero_floor is None else 1,
                                                ctypes.c_float(0.0 if above_zero_floor is None else float(above_zero_floor)),
-                                               _ptr(out), _ptr(status), _stream(Ptxs.device))
+                                               int(max_graph_rows), _ptr(out), _ptr(status), _stream(Ptxs.device))
     _lib.check(rc, "escat_infogain_divergence_f32")
     if check and B and bool(status[:B].any()):
         bad = torch.nonzero(status[:B]).reshape(-1).tolist()

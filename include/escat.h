@@ -285,11 +285,14 @@ int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const in
  *   metric     0 = KL(q_T || p_t) = sum q (log q - log(p + 1e-12)) (:857-863), 1 = L1 (:866)
  *   fixed_floor / floor_val   1: above_zero_floor = floor_val (divergence_metric_kwargs['above_zero_floor']);
  *              0: midpoint of the lowest and second-lowest distinct value of each column (nn_utilities.py:202-245)
+ *   max_graph_rows  largest graph_ptr[g+1] - graph_ptr[g] if the caller knows it (the kernel then keeps each graph in
+ *              registers and reads W once; it must be an upper bound), 0 = unknown (three passes from L2)
  *   out        (n_graphs, F-1-start, C) fp32, summed over the graph's rows (:891-898)
  *   status     (n_graphs) int32, set to 1 where a column cannot be normalised (no variance / zero floor: the
  *              reference fails with a TypeError there); the corresponding out entries are NaN */
 int escat_infogain_divergence_f32(const float *W, const int32_t *graph_ptr, int64_t n_graphs, int C, int F, int start,
-                                  int metric, int fixed_floor, float floor_val, float *out, int32_t *status, void *stream);
+                                  int metric, int fixed_floor, float floor_val, int max_graph_rows, float *out,
+                                  int32_t *status, void *stream);
 
 /* host utility (no GPU): Jenkins lookup3 "hashlittle", the checksum of HDF5 version-2 object headers
  * (esc_gnn_amd/hdf5_min.py, the writer of the reference's operator layout). */
