@@ -4,6 +4,9 @@ scattering hot path behind the reference's own Python signatures.
 
     get_Batch_Wjxs   <- pyg_utilities.get_Batch_Wjxs          (pyg_utilities.py:283)
     scatter          <- ESCGNNModular._scatter                (models/escgnn_modular.py:309)
+    get_vector_invariants         <- ESCGNNModular._get_vector_invariants (models/escgnn_modular.py:403)
+    calc_infogain_wavelet_scales  <- models.infogain.calc_infogain_wavelet_scales (models/infogain.py:172)
+    process_pyg_data / build_PQ_batch  <- data_processing.process_pyg_data (esc_gnn_amd.process_pyg_data)
     ScatterOperator  canonical device CSR / BSR-3 form of P / Q
     OperatorBatch    a mini-batch drawn (by part ids, no copy) from a stored ScatterOperator
 
@@ -14,3 +17,5 @@ from .operators import ScatterOperator, OperatorBatch, as_operator           # n
 from .scales import ChainPlan, plan_chain                     # noqa: F401
 from .pyg_utilities import get_Batch_Wjxs                     # noqa: F401
 from .scatter import scatter, escat_scatter                   # noqa: F401
+from .invariants import get_vector_invariants                 # noqa: F401
+from .infogain import calc_infogain_wavelet_scales            # noqa: F401
