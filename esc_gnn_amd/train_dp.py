@@ -32,7 +32,7 @@ class ScatteringHead(nn.Module):
     def forward(self, Ws: torch.Tensor, inv: torch.Tensor, graph_id: torch.Tensor, n_graphs: int) -> torch.Tensor:
         N = Ws.shape[0]
         feats = torch.cat([Ws.reshape(N, -1), inv], dim=1)                             # (N, C*W + W*(1+m))
-        y = self.mlp(self.bn(feats)).squeeze(-1)
+        y = self.mlp(self.bn(feats)).squeeze(-1).float()
         out = torch.zeros(n_graphs, device=y.device, dtype=y.dtype).index_add_(0, graph_id, y)
         cnt = torch.zeros(n_graphs, device=y.device, dtype=y.dtype).index_add_(0, graph_id, torch.ones_like(y))
         return out / cnt.clamp(min=1)
@@ -41,13 +41,14 @@ class ScatteringHead(nn.Module):
 class DPTrainer:
     POOL_STATS = ('percentiles', 'min', 'max', 'mean')        # the reference's default neighbor_kwargs (:431-434)
 
-    def __init__(self, C: int, diffusion_kwargs: Dict, lr: float = 1e-3, device=None):
+    def __init__(self, C: int, diffusion_kwargs: Dict, lr: float = 1e-3, device=None, amp_bf16: bool = False):
         from .scales import plan_chain
         from .invariants import quantile_levels
         F = plan_chain(**{k: v for k, v in diffusion_kwargs.items()}).F
         W = 1 + F + F * (F - 1) // 2
         m = 3 + len(quantile_levels(0.2))
         self.kw = {"diffusion_kwargs": diffusion_kwargs}
+        self.amp_bf16 = amp_bf16          # head GEMMs in bf16 (Accelerate's mixed_precision='bf16'); scattering stays fp32
         self.model = ScatteringHead(C * W, W * (1 + m)).to(device)
         self.bucket = FlatGradBucket(self.model.parameters())
         self.opt = torch.optim.AdamW(self.model.parameters(), lr=lr)
@@ -61,8 +62,9 @@ class DPTrainer:
             Wv = scatter(track="vector", x0=x_v, P_or_Q=Q, kwargs=self.kw)               # (N, 1, 3, W)
             inv = get_vector_invariants(Wv.permute(0, 3, 1, 2).contiguous(), edge_index, self.POOL_STATS, 0.2)   # (N, W', 1, d) in
         self.bucket.zero()
-        pred = self.model(Ws, inv, graph_id, n_graphs)
-        loss = torch.nn.functional.mse_loss(pred, target)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp_bf16):
+            pred = self.model(Ws, inv, graph_id, n_graphs)
+        loss = torch.nn.functional.mse_loss(pred.float(), target)
         loss.backward()                       # grads land in the flat bucket (p.grad are views of it)
         self.bucket.allreduce_mean()          # the step's only collective
         self.opt.step()

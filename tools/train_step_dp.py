@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--amp", action="store_true", help="bf16 autocast for the (plain PyTorch) head; scattering stays fp32")
     args = ap.parse_args()
     import numpy as np, torch, torch.distributed as dist
     from esc_gnn_amd import synthetic
@@ -39,7 +40,7 @@ def main():
     # synthetic graph-level target: the cloud's diameter-like extent (max coordinate range)
     target = torch.from_numpy((clouds.max(1) - clouds.min(1)).max(1).astype(np.float32)).to(dev)
     torch.manual_seed(0)          # identical initial weights on every rank
-    tr = DPTrainer(C=3, diffusion_kwargs=dict(scales_type="dyadic", J=4, include_lowpass=True), device=dev)
+    tr = DPTrainer(C=3, diffusion_kwargs=dict(scales_type="dyadic", J=4, include_lowpass=True), device=dev, amp_bf16=args.amp)
     b["P"].csr().sell(); b["Q"].bsr3().sell()
     losses = []
     for _ in range(args.warmup):
@@ -54,7 +55,7 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps({"workload": f"cfg4: DP training step, {args.graphs} graphs x {args.nodes} nodes per GPU, k={args.k}, J=4",
-                          "n_gpus": world, "graphs_per_s": args.graphs * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                          "head_precision": "bf16 autocast" if args.amp else "fp32", "n_gpus": world, "graphs_per_s": args.graphs * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                           "params": tr.n_params(), "loss_first": float(losses[0]), "loss_last": float(losses[-1])}))
     if world > 1: dist.destroy_process_group()
 
