@@ -10,6 +10,7 @@ torch.triu_indices order (:507-516)].  No modulus anywhere (SURVEY.md finding 1)
 
 `escat_scatter` has the reference method's exact keyword signature so that it
 can replace it on the model class:  ESCGNNModular._scatter = escat_scatter
+(and  model.escat_cache = ScatteringCache()  removes the redundant epoch-0 pass).
 """
 import ctypes
 import torch
@@ -76,7 +77,48 @@ def _scatter_rows(x, P_or_Q, dkw, second_order):
     return _Orders.apply(x, W1, second_order)                                              # (rows, C, W)
 
 
-def scatter(*, track, x0, P_or_Q, kwargs, ablate_second_order_wavelets=False):
+class ScatteringCache:
+    """Per-batch memo of `scatter` results.  The scattering has no learnable parameter, so a second
+    call on the same batch tensors returns the same coefficients: at epoch 0 the reference runs `_scatter` twice per
+    batch and track (run_epoch_zero_methods then forward, training/train.py:312-319, models/escgnn_modular.py:802-838),
+    and evaluation loops revisit batches.  One entry per track; an entry holds references to its inputs, so object
+    identity is a safe key, and x0's version counter catches in-place edits.  Gradient-carrying calls are never cached."""
+
+    def __init__(self):
+        self._entries = {}
+        self.hits = 0
+        self.misses = 0
+
+    @staticmethod
+    def _key(x0, P_or_Q, dkw, ablate):
+        ds = dkw.get('diffusion_scales', None)
+        ds = tuple(ds.reshape(-1).tolist()) + tuple(ds.shape) if torch.is_tensor(ds) else ds
+        return (x0.data_ptr(), x0._version, tuple(x0.shape), id(P_or_Q), dkw.get('scales_type', 'dyadic'), ds,
+                dkw.get('J', 5), dkw.get('include_lowpass', True), bool(ablate))
+
+    def lookup(self, track, x0, P_or_Q, dkw, ablate):
+        e = self._entries.get(track)
+        if e is not None and e[0] == self._key(x0, P_or_Q, dkw, ablate) and e[1] is x0 and e[2] is P_or_Q:
+            self.hits += 1
+            return e[3]
+        self.misses += 1
+        return None
+
+    def store(self, track, x0, P_or_Q, dkw, ablate, W):
+        self._entries[track] = (self._key(x0, P_or_Q, dkw, ablate), x0, P_or_Q, W)
+
+    def clear(self):
+        self._entries.clear()
+
+
+def scatter(*, track, x0, P_or_Q, kwargs, ablate_second_order_wavelets=False, cache: ScatteringCache = None):
+    if cache is not None and not (torch.is_grad_enabled() and x0.requires_grad):
+        W = cache.lookup(track, x0, P_or_Q, kwargs['diffusion_kwargs'], ablate_second_order_wavelets)
+        if W is None:
+            W = scatter(track=track, x0=x0, P_or_Q=P_or_Q, kwargs=kwargs,
+                        ablate_second_order_wavelets=ablate_second_order_wavelets)
+            cache.store(track, x0, P_or_Q, kwargs['diffusion_kwargs'], ablate_second_order_wavelets, W)
+        return W
     if track == 'scalar':
         return _scatter_rows(x0, P_or_Q, kwargs['diffusion_kwargs'], not ablate_second_order_wavelets)     # (N, C, W)
     N, d = x0.shape
@@ -86,6 +128,8 @@ def scatter(*, track, x0, P_or_Q, kwargs, ablate_second_order_wavelets=False):
 
 
 def escat_scatter(self, *, track, x0, P_or_Q, kwargs):
-    """method form: assign to ESCGNNModular._scatter (reads self.ablate_second_order_wavelets)."""
+    """method form: assign to ESCGNNModular._scatter (reads self.ablate_second_order_wavelets).  If the model carries
+    an `escat_cache` attribute (a ScatteringCache) repeated calls on the same batch reuse the coefficients."""
     return scatter(track=track, x0=x0, P_or_Q=P_or_Q, kwargs=kwargs,
-                   ablate_second_order_wavelets=bool(getattr(self, 'ablate_second_order_wavelets', False)))
+                   ablate_second_order_wavelets=bool(getattr(self, 'ablate_second_order_wavelets', False)),
+                   cache=getattr(self, 'escat_cache', None))

@@ -128,6 +128,17 @@ def test_scatter_vs_goldens(sg):
     Wc = escat_scatter(M(), track="scalar", x0=xs, P_or_Q=P, kwargs=kwc)
     rc = sg["scatter_scalar_custom"]
     assert Wc.shape == rc.shape and np.abs(Wc.cpu().numpy() - rc).max() <= 2e-5 * np.abs(rc).max()
+    # per-batch cache: the epoch-0 double call (run_epoch_zero_methods + forward) computes once
+    from esc_gnn_amd.scatter import ScatteringCache
+    m = M(); m.escat_cache = ScatteringCache()
+    W1 = escat_scatter(m, track="scalar", x0=xs, P_or_Q=P, kwargs=kw)
+    W2 = escat_scatter(m, track="scalar", x0=xs, P_or_Q=P, kwargs=kw)
+    V1 = escat_scatter(m, track="vector", x0=xv, P_or_Q=Q, kwargs=kw)
+    V2 = escat_scatter(m, track="vector", x0=xv, P_or_Q=Q, kwargs=kw)
+    assert W2 is W1 and V2 is V1 and m.escat_cache.hits == 2 and m.escat_cache.misses == 2
+    assert torch.equal(W1, scatter(track="scalar", x0=xs, P_or_Q=P, kwargs=kw))
+    xg = xs.clone().requires_grad_(True)
+    assert escat_scatter(m, track="scalar", x0=xg, P_or_Q=P, kwargs=kw).requires_grad and m.escat_cache.hits == 2
     # gradient of the orders-0/1/2 epilogue against torch autograd of the same formula
     xs2 = xs.clone().requires_grad_(True)
     W = scatter(track="scalar", x0=xs2, P_or_Q=P, kwargs=kw)

@@ -242,3 +242,29 @@ def test_sort_free_ingest_of_reference_layouts():
     Pd = torch.sparse_coo_tensor(torch.tensor([[0, 0, 1], [0, 0, 1]]), torch.tensor([1.0, 2.0, 3.0]), (2, 2))
     assert ScatterOperator._from_emission_order(Pd, 2) is None
     assert ScatterOperator.from_torch(Pd, allow_cpu=True).csr().val.tolist() == [3.0, 3.0]
+
+
+def test_scattering_cache_keys():
+    """per-batch memo of scatter results: identity + version + settings are the key."""
+    from esc_gnn_amd.scatter import ScatteringCache
+    c = ScatteringCache()
+    x, op = torch.randn(6, 2), object()
+    dkw = dict(scales_type="dyadic", J=4, include_lowpass=True)
+    assert c.lookup("scalar", x, op, dkw, False) is None
+    W = torch.zeros(6, 2, 22)
+    c.store("scalar", x, op, dkw, False, W)
+    assert c.lookup("scalar", x, op, dkw, False) is W
+    assert c.lookup("vector", x, op, dkw, False) is None                  # one entry per track
+    assert c.lookup("scalar", x, op, dict(dkw, J=3), False) is None       # other settings
+    assert c.lookup("scalar", x, op, dkw, True) is None
+    assert c.lookup("scalar", x.clone(), op, dkw, False) is None          # another tensor
+    assert c.lookup("scalar", x, object(), dkw, False) is None            # another operator
+    x.add_(1.0)                                                           # in-place edit bumps the version counter
+    assert c.lookup("scalar", x, op, dkw, False) is None
+    ds = torch.tensor([0, 1, 2, 4])
+    c.store("scalar", x, op, dict(scales_type="custom", diffusion_scales=ds), False, W)
+    assert c.lookup("scalar", x, op, dict(scales_type="custom", diffusion_scales=ds.clone()), False) is W
+    assert c.lookup("scalar", x, op, dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 5])), False) is None
+    assert c.hits == 2 and c.misses == 8
+    c.clear()
+    assert c.lookup("scalar", x, op, dict(scales_type="custom", diffusion_scales=ds), False) is None
