@@ -16,6 +16,7 @@ purpose:
     :448-450, :464);
   * scales_type=None with no scales is the single product P^1 x (:476-479).
 """
+import functools
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 import torch
@@ -37,6 +38,33 @@ def _as_int_list(t) -> List:
 
 
 def plan_chain(scales_type='dyadic', diffusion_scales=None, J=5, include_lowpass=True) -> ChainPlan:
+    """memoised front end (the plan depends on a handful of small values; building it costs ~10 us per call)."""
+    ds = diffusion_scales
+    if torch.is_tensor(ds):
+        if ds.numel() > 4096:
+            return _plan_chain(scales_type, ds, J, include_lowpass)
+        key = ('t', tuple(ds.shape), tuple(ds.detach().reshape(-1).tolist()))
+    elif isinstance(ds, (list, tuple)):
+        key = ('l', tuple(tuple(r) if isinstance(r, (list, tuple)) else r for r in ds))
+    else:
+        key = ('v', ds)
+    try:
+        return _plan_cached(scales_type, key, J, bool(include_lowpass))
+    except TypeError:                  # unhashable argument: plan it directly (and raise what planning raises)
+        return _plan_chain(scales_type, ds, J, include_lowpass)
+
+
+@functools.lru_cache(maxsize=256)
+def _plan_cached(scales_type, key, J, include_lowpass):
+    kind, *rest = key
+    if kind == 't':
+        ds = torch.tensor(rest[1], dtype=torch.long).reshape(rest[0])
+    else:
+        ds = rest[0]
+    return _plan_chain(scales_type, ds, J, include_lowpass)
+
+
+def _plan_chain(scales_type='dyadic', diffusion_scales=None, J=5, include_lowpass=True) -> ChainPlan:
     ds = diffusion_scales
     is_dyadic_str = isinstance(ds, str) and ds == 'dyadic'
     if ds is not None and not is_dyadic_str and isinstance(ds, str):
