@@ -25,12 +25,12 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _close(a, ref, rtol=RTOL):
+def _close(a, ref, rtol=RTOL, atol=1e-30):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
     assert a.shape == ref.shape, (a.shape, ref.shape)
     for f in range(ref.shape[-1]):
         d = np.abs(a[..., f] - ref[..., f]).max()
-        assert d <= rtol * np.abs(ref[..., f]).max() + 1e-30, (f, d, np.abs(ref[..., f]).max())
+        assert d <= rtol * np.abs(ref[..., f]).max() + atol, (f, d, np.abs(ref[..., f]).max())
 
 
 def _ops(sg, dev):
@@ -588,3 +588,83 @@ def test_empty_and_degenerate_inputs():
         get_Batch_Wjxs(torch.ones(4, 1, device=dev), op, J=1)      # size mismatch
     with pytest.raises(TypeError):
         get_Batch_Wjxs(torch.ones(3, 1, device=dev, dtype=torch.float64), op, J=1)
+
+
+def test_cfg1_full_size_vs_c_oracle(oracle_lib):
+    """BASELINE cfg1 at its full size (500 graphs x 200 nodes, k=5, seed 457892): pos (C=3), the two Dirac columns
+    (C=2, farthest / nearest node from the centroid, ellipsoid_data_classes.py:255-262) and the vector track, with the
+    dyadic J=4 bank and the shipped custom scales [0,1,2,4,6,8,16], forward and backward, against the plain-C oracle.
+    A late band is the difference of two powers of the input's magnitude and 30x smaller than them here (smooth
+    coordinate signal), so besides 1e-5 of the band the bound carries 5e-7 of max|input| (two fp32 ulps of the powers)."""
+    from esc_gnn_amd import get_Batch_Wjxs, plan_chain, ScatterOperator, synthetic
+    dev = _dev()
+    B, n = 500, 200
+    b = synthetic.ellipsoid_batch(B, n, 5, seed=457892)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    pos = torch.from_numpy(b["pos"])
+    r = (pos.view(B, n, 3) - pos.view(B, n, 3).mean(1, keepdim=True)).norm(dim=2)
+    dirac = torch.zeros(B, n, 2)
+    dirac[torch.arange(B), r.argmax(1), 0] = 1.0
+    dirac[torch.arange(B), r.argmin(1), 1] = 1.0
+    dirac = dirac.view(B * n, 2)
+    g = torch.Generator().manual_seed(1)
+    for kw in (dict(scales_type="dyadic", J=4), dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16]))):
+        plan = plan_chain(**kw)
+        ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+        for xs in (pos, dirac):
+            xg = xs.to(dev).requires_grad_(True)
+            W = get_Batch_Wjxs(xg, opP, **kw)
+            _close(W, co.c_chain_csr(b["rowptr"], b["col"], b["pval"], xs.numpy(), ev, plan.T, plan.F),
+                   atol=5e-7 * float(xs.abs().max()))
+            gup = torch.randn(W.shape, generator=g)
+            (W * gup.to(dev)).sum().backward()
+            _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gup.numpy(), ev, plan.T), rtol=2e-5)
+        xv = pos.reshape(-1, 1)
+        xvg = xv.to(dev).requires_grad_(True)
+        Wq = get_Batch_Wjxs(xvg, opQ, **kw)
+        _close(Wq, co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F),
+               atol=5e-7 * float(xv.abs().max()))
+        gq = torch.randn(Wq.shape, generator=g)
+        (Wq * gq.to(dev)).sum().backward()
+        _close(xvg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T), rtol=2e-5)
+
+
+def test_properties_at_full_cfg2_size():
+    """BASELINE cfg2 at its full size (4096 graphs x 500 nodes, k=10; operators from the GPU builder): the
+    size-independent properties of test_properties_at_benchmark_size on both tracks, plus orders 0/1/2."""
+    from esc_gnn_amd import get_Batch_Wjxs, scatter, synthetic
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    dev = _dev()
+    B, n = 4096, 500
+    pos = torch.from_numpy(synthetic.ellipsoid_clouds(B, n, seed=457893).reshape(-1, 3)).to(dev)
+    gp = torch.arange(B + 1, dtype=torch.int32, device=dev) * n
+    b = build_PQ_batch(pos, gp, 10, {"kernel": "gaussian", "gaussian_eps": 0.05})
+    opP, opQ, N = b["P"], b["Q"], B * n
+    W1 = get_Batch_Wjxs(torch.full((N, 2), 3.0, device=dev), opP, J=4)
+    assert W1[..., :-1].abs().max() < 1e-5 and (W1[..., -1] - 3.0).abs().max() < 1e-5
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x, y = torch.randn(N, 3, device=dev, generator=gen), torch.randn(N, 3, device=dev, generator=gen)
+    Wx, Wy = get_Batch_Wjxs(x, opP, J=4), get_Batch_Wjxs(y, opP, J=4)
+    Wl = get_Batch_Wjxs(2.0 * x - 0.5 * y, opP, J=4)
+    assert (Wl - (2.0 * Wx - 0.5 * Wy)).abs().max() <= 1e-5 * Wl.abs().max()
+    assert (Wx.sum(-1) - x).abs().max() < 2e-5
+    for op, xin in ((opP, x), (opQ, pos.reshape(-1, 1))):
+        xin = xin.clone().requires_grad_(True)
+        W = get_Batch_Wjxs(xin, op, J=4)
+        G = torch.randn(W.shape, device=dev, generator=gen)
+        (W * G).sum().backward()
+        lhs = (W.detach().double() * G.double()).sum()
+        rhs = (xin.detach().double() * xin.grad.double()).sum()
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+    Wq = get_Batch_Wjxs(pos.reshape(-1, 1), opQ, J=4)
+    assert (Wq.sum(-1).reshape(-1) - pos.reshape(-1)).abs().max() < 2e-5
+    # orders 0/1/2: slot 0 is the input, slots 1..F the bank, the rest the triu products of the bank
+    kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=4, include_lowpass=True)}
+    S = scatter(track="scalar", x0=x, P_or_Q=opP, kwargs=kw)
+    F = Wx.shape[-1]
+    iu = torch.triu_indices(F, F, 1, device=dev)
+    assert S.shape == (N, 3, 1 + F + F * (F - 1) // 2)
+    assert torch.equal(S[..., 0], x) and torch.equal(S[..., 1:1 + F], Wx)
+    assert (S[..., 1 + F:] - Wx[..., iu[0]] * Wx[..., iu[1]]).abs().max() <= 1e-6 * S.abs().max()
