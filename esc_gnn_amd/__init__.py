@@ -13,7 +13,7 @@ scattering hot path behind the reference's own Python signatures.
 The compute lives in libescat.so (esc_gnn_amd/csrc, C ABI in include/escat.h).
 """
 from ._lib import EscatError, load as load_library            # noqa: F401
-from .operators import ScatterOperator, OperatorBatch, as_operator           # noqa: F401
+from .operators import ScatterOperator, OperatorBatch, FactoredVectorOperator, as_operator           # noqa: F401
 from .scales import ChainPlan, plan_chain                     # noqa: F401
 from .pyg_utilities import get_Batch_Wjxs                     # noqa: F401
 from .scatter import scatter, escat_scatter                   # noqa: F401

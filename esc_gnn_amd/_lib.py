@@ -27,7 +27,7 @@ class EscatEvent(ctypes.Structure):
 class EscatSell(ctypes.Structure):
     _fields_ = [("val", ctypes.c_void_p), ("lc", ctypes.c_void_p), ("lane_meta", ctypes.c_void_p),
                 ("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("slices_per_part", ctypes.c_int32),
-                ("reserved", ctypes.c_int32),
+                ("val_planes", ctypes.c_int32),
                 ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p),
                 ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32),
                 ("orders", ctypes.c_int32)]
@@ -51,6 +51,7 @@ SIGNATURES = {
     "escat_neighbor_pool_bwd_f32": (ci, [vp, vp, i64, ci, ci, ci, vp, vp, vp, vp]),
     "escat_vector_invariants_f32": (ci, [vp, vp, vp, i64, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     "escat_vector_invariants_bwd_f32": (ci, [vp, vp, vp, i64, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "escat_rotate_frames_f32": (ci, [vp, vp, vp, i64, ci, ci, vp]),
     "escat_infogain_divergence_f32": (ci, [vp, vp, i64, ci, ci, ci, ci, ci, ctypes.c_float, ci, vp, vp, vp]),
     "escat_lookup3": (ctypes.c_uint32, [ctypes.c_char_p, sz, ctypes.c_uint32]),
     "escat_build_workspace_bytes": (sz, [i64, ci, ci]),

@@ -542,6 +542,7 @@ struct SellDev {
     const int *part_list, *part_row0;             // optional: the launch covers parts part_list[i], whose rows of the
     int dmax, nsl;                                // dense operands start at part_row0[i] (a batch drawn from a store)
     int orders;                                   // forward only: 0 = the bank; 1 = [x | bank]; 2 = [x | bank | pair products]
+    int planes;                                   // CSR packs: 1 = one value per entry, 3 = one per channel (OpCsrV3)
 };
 
 #define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
@@ -719,6 +720,67 @@ template <int CC, int DMAX> struct OpCsr {
             const float *x = xa + (col[e] - gs) * CP;
 #pragma unroll
             for (int c = 0; c < CC; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
+        }
+    }
+};
+
+
+// CSR with one value PER CHANNEL (three of them): y[i][c] = sum_j v[i,j][c] * x[j][c].  This is the vector operator in its
+// factored form: Q = D Pt D^T with D = blockdiag(O_i) and Pt_c[i,j] = p_ij * sign<O_i[:,c], O_j[:,c]> (what
+// process_pyg_data's column_dot alignment builds, process_pyg_data.py:306-313, :492), so Q^t = D Pt^t D^T and the chain
+// runs in the local frames on P's pattern with 12 B of values per nonzero instead of 36.  Same LDS layout and gathers
+// as OpCsr<3>; pack layout val[((doff_s + d) * 3 + c) * 64 + lane] (escat_sell.val_planes = 3).
+template <int DMAX> struct OpCsrV3 {
+    static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
+    static constexpr int C = 3, CP = 4;
+    static constexpr int MINW = 4;
+    float v[DMAX][3];
+    unsigned lc[DMAX / 2];
+    __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)   // see OpBsr3::load
+    {
+        const int wl = w > 0 ? w - 1 : 0;
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            const float *p = sd.val + (int64_t)(doff + (d < wl ? d : wl)) * 192 + lane;
+            v[d][0] = p[0]; v[d][1] = p[64]; v[d][2] = p[128];
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < DMAX / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
+    }
+    __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    template <int W>
+    __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[3]) const
+    {
+        XVec<4> xv[GATHER_AHEAD + 1];
+#pragma unroll
+        for (int d = 0; d < GATHER_AHEAD && d < W; ++d) xv[d].load(xa + row_of(d) * 4u);
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            if (d + GATHER_AHEAD < W) xv[(d + GATHER_AHEAD) % (GATHER_AHEAD + 1)].load(xa + row_of(d + GATHER_AHEAD) * 4u);
+            const XVec<4> &x = xv[d % (GATHER_AHEAD + 1)];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = fmaf(v[d][c], x.v[c], acc[c]);
+            asm volatile("" :: "v"(x.v[3]));          // keep the gather a ds_read_b128
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, float (&acc)[3]) const
+    {
+        if constexpr (W <= DMAX) {
+            if (w2 == W / 2) gather_w<W>(xa, acc);
+            else dispatch<W + 2>(w2, xa, acc);
+        }
+    }
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[3]) const { dispatch<2>((w + 1) >> 1, xa, acc); }
+    static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
+                                                int gs, const float *xa, float (&acc)[3])
+    {
+        for (int e = e0; e < e0 + n; ++e) {
+            const float *x = xa + (col[e] - gs) * 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = fmaf(val[(int64_t)e * 3 + c], x[c], acc[c]);
         }
     }
 };
@@ -1288,7 +1350,7 @@ static int chain_path_override()
     return 0;
 }
 
-#define LIST_NEEDS_REG "escat_sell.part_list / .orders need the register-resident path (a packed operator whose parts have <= 512 rows and fit LDS)"
+#define LIST_NEEDS_REG "escat_sell.part_list / .orders / .val_planes = 3 need the register-resident path (a packed operator whose parts have <= 512 rows and fit LDS)"
 
 static int sell_to_dev(const escat_sell *sell, SellDev *sd)
 {
@@ -1302,6 +1364,9 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
     sd->part_list = sell->part_list; sd->part_row0 = sell->part_row0;
     if (sell->orders < 0 || sell->orders > 2) return fail(ESCAT_EINVAL, "escat_sell.orders=%d: 0, 1 or 2", sell->orders);
     sd->orders = sell->orders;
+    if (sell->val_planes != 0 && sell->val_planes != 1 && sell->val_planes != 3)
+        return fail(ESCAT_EINVAL, "escat_sell.val_planes=%d: 0/1 (one value per entry) or 3 (one per channel)", sell->val_planes);
+    sd->planes = sell->val_planes == 3 ? 3 : 1;
     return ESCAT_OK;
 }
 
@@ -1406,10 +1471,27 @@ static int launch_csr_sell_c(int max_rows, const int *ci, const float *v, int n_
     }
     return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: CSR packs must use 8, 16, 20, 24 or 32", sd.dmax);
 }
+template <int DMAX, bool BWD>
+static int launch_csrv3_sell_d(int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd, const float *IN,
+                               float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    if (max_rows <= 256) return launch_sell_k<OpCsrV3<DMAX>, 256, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+    return launch_sell_k<OpCsrV3<DMAX>, 512, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+}
 template <bool BWD>
 static int launch_csr_sell(int C, int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd,
                            const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
+    if (sd.planes == 3) {
+        if (C != 3) return fail(ESCAT_EINVAL, "a pack with one value per channel (val_planes = 3) needs C = 3, got %d", C);
+        switch (sd.dmax) {
+            case 8:  return launch_csrv3_sell_d<8, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+            case 16: return launch_csrv3_sell_d<16, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+            case 20: return launch_csrv3_sell_d<20, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+            case 24: return launch_csrv3_sell_d<24, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
+        }
+        return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: per-channel CSR packs must use 8, 16, 20 or 24", sd.dmax);
+    }
     switch (C) {
 #define CASE(c) case c: return launch_csr_sell_c<c, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -1447,7 +1529,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
                 if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
                 rc = launch_csr_sell<BWD>(C, max_part_rows, col, val, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
-            } else if (sell && (sell->part_list || sell->orders))
+            } else if (sell && (sell->part_list || sell->orders || sell->val_planes == 3))
                 return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
             else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);
@@ -1456,7 +1538,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
             return ESCAT_OK;
         }
     }
-    if (sell && (sell->part_list || sell->orders)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
+    if (sell && (sell->part_list || sell->orders || sell->val_planes == 3)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
     // multi-launch path
     const size_t need = (size_t)2 * n * C * sizeof(float);
     if (T > 0 && (!workspace || workspace_bytes < need))

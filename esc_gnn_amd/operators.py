@@ -124,7 +124,7 @@ def locality_order(rowptr: torch.Tensor, col: torch.Tensor, n: int, max_componen
 
 
 SELL_MAX_PART_ROWS = 512
-_SELL_DMAX = {1: (8, 16, 20, 24, 32), 9: (8, 12, 16, 20, 22)}     # register capacities the kernels are instantiated for
+_SELL_DMAX = {1: (8, 16, 20, 24, 32), 3: (8, 16, 20, 24), 9: (8, 12, 16, 20, 22)}     # register capacities the kernels are instantiated for
 # rows longer than the capacity stream their tail from L2 every step (slow for their whole workgroup), but the largest
 # BSR-3 capacity leaves the kernel short of registers: accept a capacity that leaves at most this fraction of rows a tail
 _SELL_TAIL_ROWS = 5e-5
@@ -158,7 +158,7 @@ def sell_copy_b(p, R: int):
 
 class Sell:
     """
-    SELL-64 pack of a CSR (val (nnz,)) or BSR-3 (val (nnz,3,3)) operator; layout in
+    SELL-64 pack of a CSR (val (nnz,), or (nnz,3): one value per channel) or BSR-3 (val (nnz,3,3)) operator; layout in
     include/escat.h (escat_sell).  Built with torch index ops on the operator's device;
     the slot order of every row's entries and the LDS vector copy each gather reads come
     from libescat's escat_sell_plan_slots (bank-conflict-aware, one wave per slice).
@@ -167,7 +167,10 @@ class Sell:
     def __init__(self, form):
         from . import _lib
         dev = form.rowptr.device
-        V = 9 if form.val.dim() == 3 else 1
+        V = 9 if form.val.dim() == 3 else (3 if form.val.dim() == 2 else 1)
+        if V == 3 and form.val.shape[1] != 3:
+            raise ValueError("escat: per-channel CSR values must be (nnz, 3)")
+        self.val_planes = V if V == 3 else 1
         caps = _SELL_DMAX[V]
         deg_all = (form.rowptr[1:] - form.rowptr[:-1]).long()
         hist = torch.bincount(deg_all.clamp(max=caps[-1] + 1), minlength=caps[-1] + 2).cumsum(0)
@@ -224,6 +227,11 @@ class Sell:
             for sp, q in enumerate(_BSR3_PIECE_ORDER):      # stored position sp holds block entry q (row-major)
                 dst = drow * 576 + (sp // 4) * 256 + (lane * 4 + sp % 4 if sp < 8 else lane)
                 val[dst] = src[:, q]
+        elif V == 3:
+            val = torch.zeros((total_d + 1) * 192, dtype=torch.float32, device=dev)
+            src = form.val[e_k]
+            for c in range(3):
+                val[(drow * 3 + c) * 64 + lane] = src[:, c]
         else:
             val = torch.zeros((total_d + 1) * 64, dtype=torch.float32, device=dev)
             val[drow * 64 + lane] = form.val[e_k]
@@ -329,7 +337,7 @@ class _Csr:
 
     def sell_global(self):
         """whole-operator pack with global columns for the multi-launch path (BSR-3 only)."""
-        if self._sell_g is None and self.val.dim() == 3 and self.nnz > 0:
+        if self._sell_g is None and self.val.dim() == 3 and self.nnz > 0:   # (nnz, 3, 3) only
             self._sell_g = SellGlobal(self)
         return self._sell_g
 
@@ -654,9 +662,47 @@ def _validate(rowptr, col, n):
         raise ValueError("column index out of range")
 
 
+class FactoredVectorOperator:
+    """
+    The vector diffusion operator in factored form, Q = D Pt D^T (opt-in; the default remains BSR-3).
+
+    process_pyg_data builds Q_ij = p_ij O_i S_ij O_j^T with S_ij = diag(sign<O_i[:,c], O_j[:,c]>) (column_dot alignment,
+    data_processing/process_pyg_data.py:306-313, :492; S = I without sign enforcement).  With D = blockdiag(O_i), which
+    is orthogonal, Q = D Pt D^T where Pt is P's pattern with one signed value per frame column, Pt_c[i,j] = p_ij s_ij,c.
+    Hence Q^t = D Pt^t D^T for every t: a chain on Q is one rotation into the local frames, the SAME chain on Pt (a
+    3-channel scalar operator with 12 B of values per nonzero instead of 36), and one rotation back per band.
+    Only operators with that structure qualify (built here from the frames; not the 'procrustes' alignment, not values
+    that were rounded to fp16 in storage).  Results agree with the BSR-3 chain to fp32 rounding (tests state 1e-5).
+
+    frames (N, 3, 3): columns are the frame vectors O_i[:, c];  signed: ScatterOperator over N rows, val (nnz, 3).
+    """
+
+    def __init__(self, frames: torch.Tensor, signed: "ScatterOperator"):
+        if frames.dim() != 3 or frames.shape[1:] != (3, 3) or frames.shape[0] != signed.n:
+            raise ValueError("escat: frames must be (N, 3, 3) with N = rows of the signed operator")
+        self.frames = frames.to(torch.float32).contiguous()
+        self.signed = signed
+        self.n = 3 * signed.n              # scalar rows, like the BSR-3 operator it stands for
+        self.device = frames.device
+        self.row_perm = None
+
+    @staticmethod
+    def from_frames(rowptr, col, pval, frames, enforce_sign: bool = True, parts=None) -> "FactoredVectorOperator":
+        """rowptr/col/pval: P in CSR (diagonal included); frames (N,3,3) from the local PCA."""
+        n = frames.shape[0]
+        rp = rowptr.long()
+        rows = torch.repeat_interleave(torch.arange(n, device=frames.device), rp[1:] - rp[:-1])
+        if enforce_sign:
+            s = torch.where((frames[rows] * frames[col.long()]).sum(1) >= 0, 1.0, -1.0)       # (nnz, 3)
+            val3 = pval[:, None] * s
+        else:
+            val3 = pval[:, None].expand(-1, 3)
+        return FactoredVectorOperator(frames, ScatterOperator.from_csr(rowptr, col, val3.contiguous(), n, validate=False, parts=parts))
+
+
 def as_operator(P_sparse):
     """torch sparse tensor (or a ScatterOperator) -> ScatterOperator, cached on the tensor object."""
-    if isinstance(P_sparse, (ScatterOperator, OperatorBatch)):
+    if isinstance(P_sparse, (ScatterOperator, OperatorBatch, FactoredVectorOperator)):
         return P_sparse
     op = getattr(P_sparse, "_escat_operator", None)
     if op is None:

@@ -22,7 +22,7 @@ from typing import Any, Dict, Optional
 import torch
 
 from . import _lib
-from .operators import ScatterOperator
+from .operators import ScatterOperator, FactoredVectorOperator
 from .pyg_utilities import _ptr, _stream
 
 _KERNELS = {"gaussian": 0, "cosine_cutoff": 1, "epanechnikov": 2}
@@ -65,10 +65,12 @@ def frames_and_Q(rowptr, col, pval, pos, kernel_kwargs, use_mean_recentering=Fal
 
 def build_PQ_batch(pos: torch.Tensor, graph_ptr: torch.Tensor, k: int, local_pca_kernel_fn_kwargs: Dict[str, Any],
                    use_mean_recentering: bool = False, enforce_sign: bool = True,
-                   sing_vect_align_method: str = "column_dot", max_graph_nodes: Optional[int] = None):
+                   sing_vect_align_method: str = "column_dot", max_graph_nodes: Optional[int] = None,
+                   factored: bool = False):
     """
     pos (N,3) fp32 on the GPU, graph_ptr int32 (B+1,) node ranges.  Returns a dict with the canonical operators:
-    rowptr (N+1), col (nnz), pval (nnz), blk (nnz,3,3), frames (N,3,3), nnz, and ScatterOperators 'P', 'Q'.
+    rowptr (N+1), col (nnz), pval (nnz), blk (nnz,3,3), frames (N,3,3), nnz, and ScatterOperators 'P', 'Q'
+    (+ 'Q_factored', the same vector operator as frames + signed scalar operator, with factored=True).
     """
     if not pos.is_cuda:
         raise RuntimeError("escat: build_PQ_batch needs GPU tensors (no CPU fallback)")
@@ -93,9 +95,15 @@ def build_PQ_batch(pos: torch.Tensor, graph_ptr: torch.Tensor, k: int, local_pca
     col, pval = col[:nnz], pval[:nnz]
     frames, blk = frames_and_Q(rowptr, col, pval, pos, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
                                sing_vect_align_method)
-    return {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk, "frames": frames, "nnz": nnz, "graph_ptr": graph_ptr,
-            "P": ScatterOperator.from_csr(rowptr, col, pval, N, validate=False),
-            "Q": ScatterOperator.from_bsr3(rowptr, col, blk, N, validate=False)}
+    out = {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk, "frames": frames, "nnz": nnz, "graph_ptr": graph_ptr,
+           "P": ScatterOperator.from_csr(rowptr, col, pval, N, validate=False),
+           "Q": ScatterOperator.from_bsr3(rowptr, col, blk, N, validate=False)}
+    if factored:
+        if sing_vect_align_method != "column_dot" and enforce_sign:
+            raise ValueError("escat: only the column_dot alignment (or no sign enforcement) has the factored form")
+        # the same operator in factored form (frames + signed scalar operator), see FactoredVectorOperator
+        out["Q_factored"] = FactoredVectorOperator.from_frames(rowptr, col, pval, frames, enforce_sign)
+    return out
 
 
 def coo_parts(batch: Dict[str, Any], g: int, hdf5_tensor_dtype: str = "float16"):

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .operators import ScatterOperator, OperatorBatch, as_operator
+from .operators import ScatterOperator, OperatorBatch, FactoredVectorOperator, as_operator
 from .scales import ChainPlan, plan_chain
 
 LDS_BUDGET = 160 * 1024
@@ -79,6 +79,9 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         sell = None
     if orders and sell is None:
         raise NoFusedOrders()
+    if not use_bsr and form.val.dim() == 2 and (sell is None or C != 3):
+        raise NotImplementedError("escat: a CSR operator with one value per channel runs on the register-resident path "
+                                  "only (C = 3, parts of <= 512 rows that fit LDS)")
     if view is not None and sell is None:
         raise NotImplementedError("escat: an OperatorBatch needs the register-resident path (parts of <= 512 rows that fit LDS)")
     if view is not None and n == 0:
@@ -90,7 +93,7 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
             plist, prow0 = view.lists_for(form)
             pl, pr, nl = plist.data_ptr(), prow0.data_ptr(), int(plist.numel())
         sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(),
-                                     sell.dmax, sell.n_slices, sell.slices_per_part, 0, 0, 0, 0, pl, pr, nl, orders)
+                                     sell.dmax, sell.n_slices, sell.slices_per_part, sell.val_planes, 0, 0, 0, pl, pr, nl, orders)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
@@ -149,6 +152,34 @@ class _WaveletBank(torch.autograd.Function):
         return _run_chain(ctx.op, ctx.plan, gW.contiguous(), backward=True), None, None
 
 
+class _RotateFrames(torch.autograd.Function):
+    """Y[n, :, f] = O_n X[n, :, f]  (transpose: O_n^T), O (N,3,3), X (N,3,F): escat_rotate_frames_f32."""
+
+    @staticmethod
+    def forward(ctx, frames, X, transpose):
+        ctx.frames, ctx.transpose = frames, transpose
+        return _rotate(frames, X, transpose)
+
+    @staticmethod
+    def backward(ctx, gY):
+        return None, _rotate(ctx.frames, gY.contiguous(), not ctx.transpose), None
+
+
+def _rotate(frames, X, transpose):
+    lib = _lib.load()
+    Xc = X.contiguous()
+    Y = torch.empty_like(Xc)
+    with torch.cuda.device(Xc.device):
+        rc = lib.escat_rotate_frames_f32(_ptr(frames), _ptr(Xc), _ptr(Y), Xc.shape[0], Xc.shape[2], int(bool(transpose)),
+                                         _stream(Xc.device))
+    _lib.check(rc, "escat_rotate_frames_f32")
+    return Y
+
+
+def rotate_frames(frames: torch.Tensor, X: torch.Tensor, transpose: bool) -> torch.Tensor:
+    return _RotateFrames.apply(frames, X, transpose)
+
+
 def get_Batch_Wjxs(
     x: torch.Tensor,
     P_sparse,
@@ -183,7 +214,14 @@ def get_Batch_Wjxs(
         raise RuntimeError(f"escat: size mismatch, operator is {op.n}x{op.n} but x has {x.shape[0]} rows")
     if plan.per_channel and plan.n_channels != x.shape[1]:
         raise IndexError("index out of range: per-channel diffusion_scales rows != channels of x")
-    W = _WaveletBank.apply(x, op, plan)
+    if isinstance(op, FactoredVectorOperator):
+        if x.shape[1] != 1:
+            raise ValueError("escat: the factored vector operator takes the flattened vector feature (3N, 1)")
+        # Q^t = D Pt^t D^T: into the local frames, the chain on the signed scalar operator, every band back out
+        u = rotate_frames(op.frames, x.view(-1, 3, 1), transpose=True).view(-1, 3)
+        W = rotate_frames(op.frames, _WaveletBank.apply(u, op.signed, plan), transpose=False).view(x.shape[0], 1, -1)
+    else:
+        W = _WaveletBank.apply(x, op, plan)
     if not plan.per_channel and plan.T >= 0 and filter_stack_dim not in (-1, 2) \
             and not (diffusion_scales is None and scales_type is None):
         W = W.movedim(-1, filter_stack_dim)

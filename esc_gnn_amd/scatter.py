@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .pyg_utilities import get_Batch_Wjxs, _ptr, _stream, _chain_launch, NoFusedOrders, MAX_C
-from .operators import OperatorBatch, as_operator
+from .operators import OperatorBatch, FactoredVectorOperator, as_operator
 from .scales import plan_chain
 
 
@@ -66,7 +66,8 @@ def _scatter_rows(x, P_or_Q, dkw, second_order):
                               J=dkw.get('J', 5), include_lowpass=dkw.get('include_lowpass', True))
             op = as_operator(P_or_Q)
             base = op.base if isinstance(op, OperatorBatch) else op
-            ok = op.n == x.shape[0] and base.row_perm is None and (not plan.per_channel or plan.n_channels == x.shape[1])
+            # (a factored vector operator rotates the bank back to global coordinates before the products are formed)
+            ok = not isinstance(op, FactoredVectorOperator) and op.n == x.shape[0] and base.row_perm is None and (not plan.per_channel or plan.n_channels == x.shape[1])
             if ok:
                 # one launch: [x | bank | pair products] written by the chain's own epilogue (escat_sell.orders)
                 return _chain_launch(op, plan.events, plan.T, plan.F, x.contiguous(), x.shape[1], False,

@@ -90,7 +90,8 @@ typedef struct {
     int32_t         dmax;
     int32_t         n_slices;
     int32_t         slices_per_part;
-    int32_t         reserved;       /* 0 */
+    int32_t         val_planes;     /* CSR packs: 0/1 = one value per entry; 3 = one value per channel (C = 3):
+                                     * val[((doff_s + d)*3 + c)*64 + lane], and the entry points' `val` is (nnz, 3) */
     /* whole-operator variant for the multi-launch path of graphs that do not fit LDS (BSR-3 only), selected by
      * col32 != NULL: slices of 64 rows sorted by length inside windows, no dmax cap; val as above,
      * col32[(doff_s + d)*64 + lane] = GLOBAL block column (-1 = padding), perm[s*64 + lane] = global row (-1: none),
@@ -293,6 +294,13 @@ int escat_vector_invariants_bwd_f32(const float *v, const int32_t *src, const in
 int escat_infogain_divergence_f32(const float *W, const int32_t *graph_ptr, int64_t n_graphs, int C, int F, int start,
                                   int metric, int fixed_floor, float floor_val, int max_graph_rows, float *out,
                                   int32_t *status, void *stream);
+
+/* Rotation by the local frames O_n of the P/Q builder (data_processing/process_pyg_data.py:238-286), for the factored
+ * form of the vector operator Q = D Pt D^T (escat_sell.val_planes = 3; the reference only ever forms the blocks
+ * p_ij O_i S_ij O_j^T, :454-493, :839-847):  Y[n][a][f] = sum_c O[n][a][c] X[n][c][f]  (transpose != 0: O[n][c][a]).
+ * frames (n_nodes, 3, 3), X and Y (n_nodes, 3, F), X != Y. */
+int escat_rotate_frames_f32(const float *frames, const float *X, float *Y, int64_t n_nodes, int F, int transpose,
+                            void *stream);
 
 /* host utility (no GPU): Jenkins lookup3 "hashlittle", the checksum of HDF5 version-2 object headers
  * (esc_gnn_amd/hdf5_min.py, the writer of the reference's operator layout). */

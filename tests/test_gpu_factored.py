@@ -1,0 +1,117 @@
+"""GPU tests of the factored form of the vector operator (FactoredVectorOperator: Q = D Pt D^T, the chain on a CSR
+operator with one value per channel, escat_sell.val_planes = 3) against the BSR-3 chain on the blocks the same
+builder emits, and of its pieces (the per-channel CSR kernel, the frame rotation).  Tolerance: the chain's 1e-5 per
+filter -- the two forms differ by fp32 rounding only (blocks are rounded products of the factors)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _built(B, n, k, seed, factored=True):
+    from esc_gnn_amd import synthetic
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    pos = torch.from_numpy(synthetic.ellipsoid_clouds(B, n, seed=seed).reshape(-1, 3)).to(DEV)
+    gp = torch.arange(B + 1, dtype=torch.int32, device=DEV) * n
+    return pos, build_PQ_batch(pos, gp, k, {"kernel": "gaussian", "gaussian_eps": 0.05}, factored=factored)
+
+
+def _rel(a, b):
+    a, b = a.detach(), b.detach()
+    return float(((a - b).abs().amax(dim=tuple(range(a.dim() - 1))) / b.abs().amax(dim=tuple(range(b.dim() - 1)))).max())
+
+
+def test_rotation_kernel():
+    from esc_gnn_amd.pyg_utilities import rotate_frames
+    g = torch.Generator(device=DEV).manual_seed(0)
+    O = torch.linalg.qr(torch.randn(1000, 3, 3, device=DEV, generator=g))[0].contiguous()
+    for F in (1, 6, 17):
+        X = torch.randn(1000, 3, F, device=DEV, generator=g, requires_grad=True)
+        Y = rotate_frames(O, X, False)
+        assert (Y - torch.einsum("nac,ncf->naf", O, X)).abs().max() < 1e-6
+        Z = rotate_frames(O, X, True)
+        assert (Z - torch.einsum("nca,ncf->naf", O, X)).abs().max() < 1e-6
+        G = torch.randn_like(Y)
+        (Y * G).sum().backward()
+        assert (X.grad - torch.einsum("nca,ncf->naf", O, G)).abs().max() < 1e-6     # the adjoint is the transpose
+        assert (rotate_frames(O, rotate_frames(O, X, True), False) - X).abs().max() < 1e-5   # O O^T = I
+
+
+@pytest.mark.parametrize("B,n,k", [(64, 128, 5), (40, 500, 10), (12, 300, 30), (50, 7, 3)])
+def test_per_channel_csr_chain(B, n, k):
+    """y[i][c] = sum_j v[i,j][c] x[j][c]: the 3-plane pack == three single-channel chains, forward and backward
+    (k = 30: rows longer than the pack's 24 slots -> tails; n = 7: many tiny graphs per workgroup)."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator
+    pos, b = _built(B, n, k, seed=n + k, factored=False)
+    N = B * n
+    g = torch.Generator(device=DEV).manual_seed(1)
+    val3 = (b["pval"][:, None] * torch.where(torch.rand(b["nnz"], 3, device=DEV, generator=g) < 0.4, -1.0, 1.0)).contiguous()
+    op3 = ScatterOperator.from_csr(b["rowptr"], b["col"], val3, N, validate=False)
+    x = torch.randn(N, 3, device=DEV, generator=g)
+    for kw in (dict(J=4), dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16]))):
+        xg = x.clone().requires_grad_(True)
+        W = get_Batch_Wjxs(xg, op3, **kw)
+        G = torch.randn(W.shape, device=DEV, generator=g)
+        (W * G).sum().backward()
+        for c in range(3):
+            opc = ScatterOperator.from_csr(b["rowptr"], b["col"], val3[:, c].contiguous(), N, validate=False)
+            xc = x[:, c:c + 1].clone().requires_grad_(True)
+            Wc = get_Batch_Wjxs(xc, opc, **kw)
+            (Wc * G[:, c:c + 1]).sum().backward()
+            assert _rel(W[:, c], Wc[:, 0]) <= 2e-6
+            assert float((xg.grad[:, c] - xc.grad[:, 0]).abs().max() / xc.grad.abs().max()) <= 2e-6
+    with pytest.raises(NotImplementedError):
+        get_Batch_Wjxs(x[:, :2].contiguous(), op3, J=2)            # one value per channel: C must be 3
+
+
+@pytest.mark.parametrize("B,n,k,J", [(256, 128, 5, 4), (128, 500, 10, 4), (16, 500, 16, 6)])
+def test_factored_chain_vs_bsr3(B, n, k, J):
+    from esc_gnn_amd import get_Batch_Wjxs
+    pos, b = _built(B, n, k, seed=3 * n + k)
+    Qf, Q = b["Q_factored"], b["Q"]
+    # the factors reproduce the builder's blocks
+    rp = b["rowptr"].long()
+    rows = torch.repeat_interleave(torch.arange(B * n, device=DEV), rp[1:] - rp[:-1])
+    O, v3 = Qf.frames, Qf.signed.csr().val
+    blk = torch.einsum("eac,ec,ebc->eab", O[rows], v3, O[b["col"].long()])
+    assert (blk - b["blk"]).abs().max() < 2e-7
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(3 * B * n, 1, device=DEV, generator=g)
+    for kw in (dict(J=J), dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16])), dict(J=J, include_lowpass=False)):
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        Wf, Wq = get_Batch_Wjxs(xa, Qf, **kw), get_Batch_Wjxs(xb, Q, **kw)
+        assert Wf.shape == Wq.shape and _rel(Wf, Wq) <= 1e-5
+        G = torch.randn(Wq.shape, device=DEV, generator=g)
+        (Wf * G).sum().backward(); (Wq * G).sum().backward()
+        assert float((xa.grad - xb.grad).abs().max() / xb.grad.abs().max()) <= 1e-5
+
+
+def test_scatter_with_factored_operator():
+    from esc_gnn_amd import scatter
+    pos, b = _built(200, 128, 5, seed=9)
+    kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=4, include_lowpass=True)}
+    for abl in (False, True):
+        Sf = scatter(track="vector", x0=pos, P_or_Q=b["Q_factored"], kwargs=kw, ablate_second_order_wavelets=abl)
+        Sq = scatter(track="vector", x0=pos, P_or_Q=b["Q"], kwargs=kw, ablate_second_order_wavelets=abl)
+        assert Sf.shape == Sq.shape == (200 * 128, 1, 3, 7 if abl else 22)
+        assert _rel(Sf, Sq) <= 1e-5
+    xg = pos.clone().requires_grad_(True)
+    S = scatter(track="vector", x0=xg, P_or_Q=b["Q_factored"], kwargs=kw)
+    S.square().sum().backward()
+    xr = pos.clone().requires_grad_(True)
+    scatter(track="vector", x0=xr, P_or_Q=b["Q"], kwargs=kw).square().sum().backward()
+    assert float((xg.grad - xr.grad).abs().max() / xr.grad.abs().max()) <= 2e-5
+
+
+def test_factored_needs_the_register_path_and_column_dot():
+    from esc_gnn_amd import get_Batch_Wjxs, synthetic
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    pos = torch.from_numpy(synthetic.ellipsoid_clouds(1, 1000, seed=1).reshape(-1, 3)).to(DEV)
+    gp = torch.tensor([0, 1000], dtype=torch.int32, device=DEV)
+    b = build_PQ_batch(pos, gp, 8, {"kernel": "gaussian", "gaussian_eps": 0.05}, factored=True)
+    with pytest.raises(NotImplementedError):                      # a 1000-node graph is beyond one workgroup's 512 rows
+        get_Batch_Wjxs(pos.reshape(-1, 1), b["Q_factored"], J=2)
+    with pytest.raises(ValueError):
+        build_PQ_batch(pos, gp, 8, {"kernel": "gaussian", "gaussian_eps": 0.05}, sing_vect_align_method="procrustes", factored=True)
