@@ -233,6 +233,28 @@ def main():
                                 "P_bwd": bytes_p / (per["P_bwd"] * 1e-3) / 1e9,
                                 "Q_bwd": bytes_q / (per["Q_bwd"] * 1e-3) / 1e9},
         }
+        if world == 1:
+            # secondary, NOT the headline: the same step with the vector operator in factored form (Q = D Pt D^T:
+            # frames + a signed scalar operator, esc_gnn_amd.FactoredVectorOperator) -- same inputs, same outputs to
+            # fp32 rounding (tests/test_gpu_factored.py), 12 B of operator values per nonzero instead of 36
+            from esc_gnn_amd import FactoredVectorOperator
+            opQf = FactoredVectorOperator.from_frames(rowptr, col, pval_d, t(b["frames"]))
+            opQf.signed.csr().sell(); opQf.signed.csr_t().sell()
+
+            def step_f():
+                xs.grad = None; xv.grad = None
+                Ws = get_Batch_Wjxs(xs, opP, scales_type="dyadic", J=args.J)
+                Wv = get_Batch_Wjxs(xv, opQf, scales_type="dyadic", J=args.J)
+                Ws.backward(gs); Wv.backward(gv)
+            for _ in range(args.warmup):
+                step_f()
+            torch.cuda.synchronize(); tf0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_f()
+            torch.cuda.synchronize(); dtf = time.perf_counter() - tf0
+            out["factored_Q_variant"] = {"value": args.graphs * args.steps / dtf, "unit": "graphs/s",
+                                         "ms_per_step": dtf / args.steps * 1e3,
+                                         "note": "opt-in operator format, not the headline; see DESIGN.md (factored vector operator)"}
         if not args.no_cpu_baseline and world == 1:
             sample = min(args.cpu_sample_graphs, args.graphs)
             gps1, s1 = cpu_baseline(b, sample, args.nodes, args.J, 1)

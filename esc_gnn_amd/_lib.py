@@ -30,7 +30,7 @@ class EscatSell(ctypes.Structure):
                 ("val_planes", ctypes.c_int32),
                 ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p),
                 ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32),
-                ("orders", ctypes.c_int32)]
+                ("orders", ctypes.c_int32), ("frames", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/escat.h declares

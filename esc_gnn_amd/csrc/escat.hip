@@ -543,7 +543,8 @@ struct SellDev {
     int dmax, nsl;                                // dense operands start at part_row0[i] (a batch drawn from a store)
     int orders;                                   // forward only: 0 = the bank; 1 = [x | bank]; 2 = [x | bank | pair products]
     int planes;                                   // CSR packs: 1 = one value per entry, 3 = one per channel (OpCsrV3)
-};
+    const float *frames;                          // OpCsrV3 only, optional: (n, 3, 3) local frames; IN and RES are then in
+};                                                // global coordinates (the chain runs D Pt^t D^T instead of Pt^t)
 
 #define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
 #define GATHER_AHEAD 3     // LDS gathers in flight ahead of the FMAs
@@ -586,6 +587,7 @@ template <> struct XVec<8> { float v[8];
 //   gather(xa, w, acc)          acc += sum over slots of value * x[LDS row]   (one step)
 //   tail(...)                   entries beyond dmax, streamed
 template <int DMAX> struct OpBsr3 {
+    static constexpr bool FRAMES = false;
     static constexpr int C = 3, CP = 4, MINW = 1;
     // a block's 9 floats as the three pieces they are loaded in, ordered for packed fp32 math:
     //   b0 = (b00, b10, b01, b11)   b1 = (b02, b12, b20, b21)   b2 = b22       (bij = row i, column j of the block)
@@ -673,6 +675,7 @@ template <int DMAX> struct OpBsr3 {
 
 template <int CC, int DMAX> struct OpCsr {
     static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
+    static constexpr bool FRAMES = false;
     static constexpr int C = CC, CP = CC == 1 ? 1 : (CC == 2 ? 2 : (CC <= 4 ? 4 : 8));
     static constexpr int MINW = 4;                // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
     float v[DMAX];
@@ -733,7 +736,9 @@ template <int CC, int DMAX> struct OpCsr {
 template <int DMAX> struct OpCsrV3 {
     static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
     static constexpr int C = 3, CP = 4;
-    static constexpr int MINW = 4;
+    static constexpr int MINW = 4;                // <= 128 VGPRs (60 of them values): two 512-thread workgroups per CU
+    static constexpr int AHEAD = 2;               // gathers in flight (one fewer than OpCsr: the ring costs 4 VGPRs a stage)
+    static constexpr bool FRAMES = true;          // SellDev.frames != NULL: rotate in and out of the local frames in LDS
     float v[DMAX][3];
     unsigned lc[DMAX / 2];
     __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)   // see OpBsr3::load
@@ -753,13 +758,13 @@ template <int DMAX> struct OpCsrV3 {
     template <int W>
     __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[3]) const
     {
-        XVec<4> xv[GATHER_AHEAD + 1];
+        XVec<4> xv[AHEAD + 1];
 #pragma unroll
-        for (int d = 0; d < GATHER_AHEAD && d < W; ++d) xv[d].load(xa + row_of(d) * 4u);
+        for (int d = 0; d < AHEAD && d < W; ++d) xv[d].load(xa + row_of(d) * 4u);
 #pragma unroll
         for (int d = 0; d < W; ++d) {
-            if (d + GATHER_AHEAD < W) xv[(d + GATHER_AHEAD) % (GATHER_AHEAD + 1)].load(xa + row_of(d + GATHER_AHEAD) * 4u);
-            const XVec<4> &x = xv[d % (GATHER_AHEAD + 1)];
+            if (d + AHEAD < W) xv[(d + AHEAD) % (AHEAD + 1)].load(xa + row_of(d + AHEAD) * 4u);
+            const XVec<4> &x = xv[d % (AHEAD + 1)];
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = fmaf(v[d][c], x.v[c], acc[c]);
             asm volatile("" :: "v"(x.v[3]));          // keep the gather a ds_read_b128
@@ -837,6 +842,30 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab,
     }
     __syncthreads();
     return p;
+}
+
+// in-place rotation of a part's 3-vectors in LDS by the rows' local frames (global, L1/L2-resident: 36 B per row):
+// buf[r * rs + c * cs + f] <- sum_c' O_r[c][c'] (TR: O_r[c'][c]) buf[r * rs + c' * cs + f]; rows are independent.
+template <bool TR, int NT>
+__device__ __forceinline__ void rotate_rows(float *buf, const float *__restrict__ fr, int rows, int F, int rs, int cs)
+{
+    for (int r = threadIdx.x; r < rows; r += NT) {             // one thread per row: its frame is loaded once
+        const float *o = fr + r * 9;
+        const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7], o8 = o[8];
+        float *x = buf + r * rs;
+        for (int f = 0; f < F; ++f) {
+            const float x0 = x[f], x1 = x[cs + f], x2 = x[2 * cs + f];
+            if (TR) {
+                x[f]          = fmaf(o6, x2, fmaf(o3, x1, o0 * x0));
+                x[cs + f]     = fmaf(o7, x2, fmaf(o4, x1, o1 * x0));
+                x[2 * cs + f] = fmaf(o8, x2, fmaf(o5, x1, o2 * x0));
+            } else {
+                x[f]          = fmaf(o2, x2, fmaf(o1, x1, o0 * x0));
+                x[cs + f]     = fmaf(o5, x2, fmaf(o4, x1, o3 * x0));
+                x[2 * cs + f] = fmaf(o8, x2, fmaf(o7, x1, o6 * x0));
+            }
+        }
+    }
 }
 
 template <bool BWD, int NT>
@@ -924,7 +953,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         if (row0 < 0) row0 = gs0;
         dma_in<NT>(BWD ? slab : inb, IN + (int64_t)row0 * in_w, rows0 * in_w);
     }
-    int prev_row0 = 0, prev_rows = -1;            // part whose result is still in LDS (epilogue pending)
+    int prev_row0 = 0, prev_rows = -1, prev_gs = 0;   // part whose result is still in LDS (epilogue pending)
     for (;;) {
         // which part comes next (read now, needed after the prologue)
         const int liN = li + gridDim.x;
@@ -942,6 +971,11 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         STAMP(li, 1);
         // ... and store the previous part's result underneath the stream
         if (prev_rows >= 0) {
+            if constexpr (Op::FRAMES && !ORD) if (sd.frames) {     // back to global coordinates (uniform branch)
+                if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, F, 3 * F, F);
+                else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
+                __syncthreads();
+            }
             if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
             else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
         }
@@ -957,6 +991,11 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         if (prev_rows < 0 || (BWD && !early)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                          // every wave's copy has landed; the epilogue's LDS reads are done
         STAMP(li, 3);
+        if constexpr (Op::FRAMES && !ORD) if (sd.frames) {         // the staged input, into the local frames
+            if (!BWD) rotate_rows<true, NT>(inb, sd.frames + (int64_t)gs * 9, rows, 1, 3, 1);
+            else rotate_rows<true, NT>(slab, sd.frames + (int64_t)gs * 9, rows, F, 3 * F, F);
+            __syncthreads();
+        }
         int p = chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab, Fs, so);
         STAMP(li, 4);
 
@@ -1003,7 +1042,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 staged = true;
             }
         }
-        prev_row0 = row0; prev_rows = rows;
+        prev_row0 = row0; prev_rows = rows; prev_gs = gs;
         STAMP(li, 6);
         if (!has_next) break;
         {
@@ -1016,6 +1055,11 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         STAMP(li, 7);
         li = liN; part = partN; row0 = row0N; rt = rtN; te0 = te0N; sw = swN;
         if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
+    }
+    if constexpr (Op::FRAMES && !ORD) if (sd.frames) {
+        if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, F, 3 * F, F);
+        else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
+        __syncthreads();
     }
     if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
     else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
@@ -1367,6 +1411,9 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
     if (sell->val_planes != 0 && sell->val_planes != 1 && sell->val_planes != 3)
         return fail(ESCAT_EINVAL, "escat_sell.val_planes=%d: 0/1 (one value per entry) or 3 (one per channel)", sell->val_planes);
     sd->planes = sell->val_planes == 3 ? 3 : 1;
+    sd->frames = sell->frames;
+    if (sd->frames && sd->planes != 3) return fail(ESCAT_EINVAL, "escat_sell.frames goes with val_planes = 3");
+    if (sd->frames && sd->orders) return fail(ESCAT_EINVAL, "escat_sell.frames and .orders exclude each other");
     return ESCAT_OK;
 }
 

@@ -680,6 +680,9 @@ class FactoredVectorOperator:
     def __init__(self, frames: torch.Tensor, signed: "ScatterOperator"):
         if frames.dim() != 3 or frames.shape[1:] != (3, 3) or frames.shape[0] != signed.n:
             raise ValueError("escat: frames must be (N, 3, 3) with N = rows of the signed operator")
+        if signed.row_perm is not None:
+            raise NotImplementedError("escat: the factored vector operator runs on the register-resident path only "
+                                      "(graphs of <= 512 nodes); this operator was relabelled as one large block")
         self.frames = frames.to(torch.float32).contiguous()
         self.signed = signed
         self.n = 3 * signed.n              # scalar rows, like the BSR-3 operator it stands for

@@ -51,7 +51,7 @@ class NoFusedOrders(Exception):
     """the launch cannot fuse the orders epilogue (not on the register-resident path): the caller uses two kernels"""
 
 
-def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool, orders: int = 0) -> torch.Tensor:
+def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bool, orders: int = 0, frames=None) -> torch.Tensor:
     """one call into the C ABI for <= MAX_C channels.  inp: fwd (n,C) / bwd (n,C,F); returns fwd (n,C,F) / bwd (n,C).
     op: a ScatterOperator, or an OperatorBatch (parts of a stored operator, walked in place).
     orders (forward): 1 / 2 = return (n, C, Wtot) = [x | bank (| pair products)] from the chain's own epilogue."""
@@ -79,6 +79,8 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         sell = None
     if orders and sell is None:
         raise NoFusedOrders()
+    if frames is not None and (use_bsr or form.val.dim() != 2):
+        raise ValueError("escat: frames go with a CSR operator that has one value per channel")
     if not use_bsr and form.val.dim() == 2 and (sell is None or C != 3):
         raise NotImplementedError("escat: a CSR operator with one value per channel runs on the register-resident path "
                                   "only (C = 3, parts of <= 512 rows that fit LDS)")
@@ -93,7 +95,8 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
             plist, prow0 = view.lists_for(form)
             pl, pr, nl = plist.data_ptr(), prow0.data_ptr(), int(plist.numel())
         sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(),
-                                     sell.dmax, sell.n_slices, sell.slices_per_part, sell.val_planes, 0, 0, 0, pl, pr, nl, orders)
+                                     sell.dmax, sell.n_slices, sell.slices_per_part, sell.val_planes, 0, 0, 0, pl, pr, nl, orders,
+                                     frames.data_ptr() if frames is not None else 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
@@ -101,7 +104,7 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         # random node order where the x gather dominates), so the default multi-launch path stays unpacked.
         sg = form.sell_global()
         sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, 0, 0, sg.n_slices, 0, 0,
-                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0, 0)
+                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -150,6 +153,22 @@ class _WaveletBank(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             return None, None, None
         return _run_chain(ctx.op, ctx.plan, gW.contiguous(), backward=True), None, None
+
+
+class _FactoredBank(torch.autograd.Function):
+    """bank of the factored vector operator in one launch: x (N, 3) global coordinates -> (N, 3, F) global."""
+
+    @staticmethod
+    def forward(ctx, x, fop, plan):
+        ctx.fop, ctx.plan = fop, plan
+        return _chain_launch(fop.signed, plan.events, plan.T, plan.F, x.contiguous(), 3, False, frames=fop.frames)
+
+    @staticmethod
+    def backward(ctx, gW):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        fop, plan = ctx.fop, ctx.plan
+        return _chain_launch(fop.signed, plan.events, plan.T, plan.F, gW.contiguous(), 3, True, frames=fop.frames), None, None
 
 
 class _RotateFrames(torch.autograd.Function):
@@ -217,9 +236,13 @@ def get_Batch_Wjxs(
     if isinstance(op, FactoredVectorOperator):
         if x.shape[1] != 1:
             raise ValueError("escat: the factored vector operator takes the flattened vector feature (3N, 1)")
-        # Q^t = D Pt^t D^T: into the local frames, the chain on the signed scalar operator, every band back out
-        u = rotate_frames(op.frames, x.view(-1, 3, 1), transpose=True).view(-1, 3)
-        W = rotate_frames(op.frames, _WaveletBank.apply(u, op.signed, plan), transpose=False).view(x.shape[0], 1, -1)
+        # Q^t = D Pt^t D^T: into the local frames, the chain on the signed scalar operator, every band back out --
+        # all inside the chain kernel (escat_sell.frames); ESCAT_FACTORED_ROTATE=separate keeps the two rotation launches
+        if os.environ.get("ESCAT_FACTORED_ROTATE", "") == "separate":
+            u = rotate_frames(op.frames, x.view(-1, 3, 1), transpose=True).view(-1, 3)
+            W = rotate_frames(op.frames, _WaveletBank.apply(u, op.signed, plan), transpose=False).view(x.shape[0], 1, -1)
+        else:
+            W = _FactoredBank.apply(x.view(-1, 3), op, plan).view(x.shape[0], 1, -1)
     else:
         W = _WaveletBank.apply(x, op, plan)
     if not plan.per_channel and plan.T >= 0 and filter_stack_dim not in (-1, 2) \

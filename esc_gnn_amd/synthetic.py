@@ -97,8 +97,9 @@ def ellipsoid_batch(B, n, k, seed=457892, with_q=True, frames_seed=12345, worker
     col = np.concatenate(cols)
     pval = lazy_walk_values(rowptr, col)
     pos = clouds.reshape(B * n, 3)
-    blk = q_blocks_from_frames(rowptr, col, pval, random_frames(B * n, frames_seed)) if with_q else None
-    return dict(pos=pos, rowptr=rowptr.astype(np.int32), col=col.astype(np.int32), pval=pval, blk=blk,
+    frames = random_frames(B * n, frames_seed) if with_q else None
+    blk = q_blocks_from_frames(rowptr, col, pval, frames) if with_q else None
+    return dict(pos=pos, rowptr=rowptr.astype(np.int32), col=col.astype(np.int32), pval=pval, blk=blk, frames=frames,
                 graph_ptr=(np.arange(B + 1) * n).astype(np.int32), nnz=int(col.shape[0]), N=B * n)
 
 

@@ -113,6 +113,10 @@ typedef struct {
      * -- what escat_scatter_orders_f32 would make of the bank, without the bank's round trip through HBM.
      * Must be 0 for the backward entry points. */
     int32_t         orders;
+    /* val_planes = 3 only, optional: local frames O (n, 3, 3) of the operator's rows.  The chain then computes
+     * D Pt^t D^T (the vector operator in factored form, D = blockdiag(O)): inputs are rotated into the frames and results
+     * back out inside the kernel, in LDS.  NULL: the chain on Pt itself. */
+    const float    *frames;
 } escat_sell;
 
 /* Pack-time planning for escat_sell: for every entry e among the first dmax of its row, the slot (column of its

@@ -66,9 +66,13 @@ def test_per_channel_csr_chain(B, n, k):
         get_Batch_Wjxs(x[:, :2].contiguous(), op3, J=2)            # one value per channel: C must be 3
 
 
-@pytest.mark.parametrize("B,n,k,J", [(256, 128, 5, 4), (128, 500, 10, 4), (16, 500, 16, 6)])
-def test_factored_chain_vs_bsr3(B, n, k, J):
+@pytest.mark.parametrize("rotate", ["fused", "separate"])
+@pytest.mark.parametrize("B,n,k,J", [(256, 128, 5, 4), (128, 500, 10, 4), (16, 500, 16, 6), (700, 37, 4, 3)])
+def test_factored_chain_vs_bsr3(B, n, k, J, rotate, monkeypatch):
+    """rotate: inside the chain kernel (escat_sell.frames, the default) or as two escat_rotate_frames_f32 launches.
+    700 graphs: more parts than resident workgroups, so the pipelined prologue / epilogue of both directions runs."""
     from esc_gnn_amd import get_Batch_Wjxs
+    monkeypatch.setenv("ESCAT_FACTORED_ROTATE", rotate)
     pos, b = _built(B, n, k, seed=3 * n + k)
     Qf, Q = b["Q_factored"], b["Q"]
     # the factors reproduce the builder's blocks
