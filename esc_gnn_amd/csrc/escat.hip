@@ -111,7 +111,8 @@ __device__ __forceinline__ void emit_one(float *o /* &OUT[row, c, 0] */, float y
 
 // ------------------------------------------------------------------ multi-launch path: scalar CSR
 // MODE 0: y = A x.   MODE 1: forward step (emit y into OUT).   MODE 2: backward step (y += gathered G).
-template <int C, int G, int MODE>
+// VP = 3: one value per channel, val (nnz, 3) (the signed scalar operator of a factored vector operator, see OpCsrV3).
+template <int C, int G, int MODE, int VP = 1>
 __global__ void __launch_bounds__(256)
 k_csr_step(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
            const float *__restrict__ xin, int ldx, float *__restrict__ yout, int ldy, int64_t n,
@@ -125,10 +126,16 @@ k_csr_step(const int *__restrict__ rowptr, const int *__restrict__ col, const fl
         for (int c = 0; c < C; ++c) acc[c] = 0.f;
         const int e1 = rowptr[row + 1];
         for (int e = rowptr[row] + lg; e < e1; e += G) {
-            const float v = val[e];
             const float *x = xin + (int64_t)col[e] * ldx;
+            if constexpr (VP == 1) {
+                const float v = val[e];
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] += v * x[c];
+                for (int c = 0; c < C; ++c) acc[c] += v * x[c];
+            } else {
+                const float *v = val + (int64_t)e * VP;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += v[c] * x[c];
+            }
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = group_sum<G>(acc[c]);
@@ -1283,8 +1290,16 @@ static void launch_csr_step_G(int G, int grid_rows_hint, const int *rp, const in
 
 template <int MODE>
 static int launch_csr_step(int C, int G, const int *rp, const int *ci, const float *v, const float *xin, int ldx,
-                           float *y, int ldy, int64_t n, const StepEv &ev, float *OUT, int64_t ld_row, int F, hipStream_t st)
+                           float *y, int ldy, int64_t n, const StepEv &ev, float *OUT, int64_t ld_row, int F, hipStream_t st,
+                           int planes = 1)
 {
+    if (planes == 3) {
+        if (C != 3) return fail(ESCAT_EINVAL, "one value per channel (val_planes = 3) needs C = 3, got %d", C);
+        if (G == 4)      hipLaunchKernelGGL((k_csr_step<3, 4, MODE, 3>), dim3(grid_for(n, 64)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
+        else if (G == 8) hipLaunchKernelGGL((k_csr_step<3, 8, MODE, 3>), dim3(grid_for(n, 32)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
+        else             hipLaunchKernelGGL((k_csr_step<3, 16, MODE, 3>), dim3(grid_for(n, 16)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
+        return ESCAT_OK;
+    }
     switch (C) {
 #define CASE(c) case c: launch_csr_step_G<c, MODE>(G, 0, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F, st); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -1565,13 +1580,19 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
     const int G = pick_G(n, nnz);
 
     const int force = chain_path_override();
-    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3) {
+    // one value per channel: val is (nnz, 3).  Runs on the register-resident path (packed) or the multi-launch path (a
+    // descriptor-only escat_sell: val = NULL, val_planes = 3); the LDS-streaming lane-group kernel has no such form.
+    const int planes = sell && sell->val_planes == 3 ? 3 : 1;
+    const bool packed = sell && sell->val != nullptr;
+    if (planes == 3 && C != 3) return fail(ESCAT_EINVAL, "one value per channel (val_planes = 3) needs C = 3, got %d", C);
+    if (sell && !packed && (sell->part_list || sell->orders || sell->frames)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
+    if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3 && (planes == 1 || packed)) {
         const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
         if (lds <= LDS_BUDGET) {
             const int CP = C == 1 ? 1 : (C == 2 ? 2 : (C <= 4 ? 4 : 8));
             int early_ = 0;
             const size_t lds_s = sell_lds_bytes(C, CP, max_part_rows, F, BWD, max_part_rows <= 256 ? 4 : 2, &early_, sell ? sell->orders : 0);
-            if (max_part_rows <= 512 && sell && force != 2 && lds_s <= LDS_BUDGET) {
+            if (max_part_rows <= 512 && packed && force != 2 && lds_s <= LDS_BUDGET) {
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
                 if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
@@ -1585,7 +1606,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
             return ESCAT_OK;
         }
     }
-    if (sell && (sell->part_list || sell->orders || sell->val_planes == 3)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
+    if (sell && (sell->part_list || sell->orders || sell->frames)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
     // multi-launch path
     const size_t need = (size_t)2 * n * C * sizeof(float);
     if (T > 0 && (!workspace || workspace_bytes < need))
@@ -1601,7 +1622,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
         for (int t = 1; t <= T; ++t) {
             rc = step_events(tab, t, &se); if (rc) return rc;
             float *y = (t & 1) ? wa : wb;
-            rc = launch_csr_step<1>(C, G, rowptr, col, val, xin, C, y, C, n, se, RES, ld_row, F, st); if (rc) return rc;
+            rc = launch_csr_step<1>(C, G, rowptr, col, val, xin, C, y, C, n, se, RES, ld_row, F, st, planes); if (rc) return rc;
             xin = y;
         }
     } else {
@@ -1613,7 +1634,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
         for (int t = T; t >= 1; --t) {
             rc = step_events(tab, t - 1, &se); if (rc) return rc;
             float *y = (t == 1) ? RES : (((T - t) & 1) ? wa : wb);
-            rc = launch_csr_step<2>(C, G, rowptr, col, val, xin, C, y, C, n, se, Gm, ld_row, F, st); if (rc) return rc;
+            rc = launch_csr_step<2>(C, G, rowptr, col, val, xin, C, y, C, n, se, Gm, ld_row, F, st, planes); if (rc) return rc;
             xin = y;
         }
         if (T == 0) { /* answer already in RES */ }

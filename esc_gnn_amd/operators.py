@@ -680,14 +680,19 @@ class FactoredVectorOperator:
     def __init__(self, frames: torch.Tensor, signed: "ScatterOperator"):
         if frames.dim() != 3 or frames.shape[1:] != (3, 3) or frames.shape[0] != signed.n:
             raise ValueError("escat: frames must be (N, 3, 3) with N = rows of the signed operator")
-        if signed.row_perm is not None:
-            raise NotImplementedError("escat: the factored vector operator runs on the register-resident path only "
-                                      "(graphs of <= 512 nodes); this operator was relabelled as one large block")
         self.frames = frames.to(torch.float32).contiguous()
         self.signed = signed
         self.n = 3 * signed.n              # scalar rows, like the BSR-3 operator it stands for
         self.device = frames.device
         self.row_perm = None
+
+    def fits_register_path(self, F: int) -> bool:
+        """True: one launch with the rotations inside the chain kernel; False (graphs too large for a workgroup): the
+        rotations are two escat_rotate_frames_f32 launches around the multi-launch chain."""
+        from .pyg_utilities import chain_lds_bytes, LDS_BUDGET
+        form = self.signed.csr()
+        return (self.signed.row_perm is None and form.n_parts > 0 and form.sell() is not None
+                and max(chain_lds_bytes(form.max_part_rows, 3, F, False, False), chain_lds_bytes(form.max_part_rows, 3, F, False, True)) <= LDS_BUDGET)
 
     @staticmethod
     def from_frames(rowptr, col, pval, frames, enforce_sign: bool = True, parts=None) -> "FactoredVectorOperator":

@@ -70,6 +70,8 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
     lds = chain_lds_bytes(form.max_part_rows, C, F, use_bsr, backward, orders)
     path = os.environ.get("ESCAT_CHAIN_PATH", "")
     fused = form.n_parts > 0 and lds <= LDS_BUDGET and not path.startswith("multi")
+    if not use_bsr and form.val.dim() == 2 and (not fused or form.sell() is None):
+        fused = False                   # one value per channel: register-resident path or multi-launch, nothing between
     ws = None
     if not fused and T > 0 and view is None:
         ws = torch.empty(lib.escat_chain_workspace_bytes(n, C) // 4, dtype=torch.float32, device=dev)
@@ -81,9 +83,11 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         raise NoFusedOrders()
     if frames is not None and (use_bsr or form.val.dim() != 2):
         raise ValueError("escat: frames go with a CSR operator that has one value per channel")
-    if not use_bsr and form.val.dim() == 2 and (sell is None or C != 3):
-        raise NotImplementedError("escat: a CSR operator with one value per channel runs on the register-resident path "
-                                  "only (C = 3, parts of <= 512 rows that fit LDS)")
+    per_channel_vals = not use_bsr and form.val.dim() == 2
+    if per_channel_vals and C != 3:
+        raise NotImplementedError("escat: a CSR operator with one value per channel takes C = 3 input channels")
+    if frames is not None and sell is None:
+        raise NotImplementedError("escat: in-kernel frame rotation needs the register-resident path")
     if view is not None and sell is None:
         raise NotImplementedError("escat: an OperatorBatch needs the register-resident path (parts of <= 512 rows that fit LDS)")
     if view is not None and n == 0:
@@ -105,6 +109,10 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         sg = form.sell_global()
         sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, 0, 0, sg.n_slices, 0, 0,
                                      sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0, 0, 0)
+        sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
+    elif per_channel_vals:
+        # no pack (graphs too large for the register path): a descriptor that only says "val is (nnz, 3)"
+        sell_struct = _lib.EscatSell(0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     with torch.cuda.device(dev):
         st = _stream(dev)
@@ -238,7 +246,7 @@ def get_Batch_Wjxs(
             raise ValueError("escat: the factored vector operator takes the flattened vector feature (3N, 1)")
         # Q^t = D Pt^t D^T: into the local frames, the chain on the signed scalar operator, every band back out --
         # all inside the chain kernel (escat_sell.frames); ESCAT_FACTORED_ROTATE=separate keeps the two rotation launches
-        if os.environ.get("ESCAT_FACTORED_ROTATE", "") == "separate":
+        if os.environ.get("ESCAT_FACTORED_ROTATE", "") == "separate" or not op.fits_register_path(plan.F):
             u = rotate_frames(op.frames, x.view(-1, 3, 1), transpose=True).view(-1, 3)
             W = rotate_frames(op.frames, _WaveletBank.apply(u, op.signed, plan), transpose=False).view(x.shape[0], 1, -1)
         else:

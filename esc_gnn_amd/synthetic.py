@@ -115,6 +115,7 @@ def single_cloud(n, k, seed=457892, workers=-1, frames_seed=12345, sort_axis=Non
         pos = pos[np.argsort(pos[:, sort_axis], kind="stable")]
     rowptr, col = knn_sym_csr(pos, k, workers=workers)
     pval = lazy_walk_values(rowptr, col)
-    blk = q_blocks_from_frames(rowptr, col, pval, random_frames(n, frames_seed))
-    return dict(pos=pos, rowptr=rowptr.astype(np.int32), col=col.astype(np.int32), pval=pval, blk=blk,
+    frames = random_frames(n, frames_seed)
+    blk = q_blocks_from_frames(rowptr, col, pval, frames)
+    return dict(pos=pos, rowptr=rowptr.astype(np.int32), col=col.astype(np.int32), pval=pval, blk=blk, frames=frames,
                 graph_ptr=np.array([0, n], dtype=np.int32), nnz=int(col.shape[0]), N=n)

@@ -109,13 +109,32 @@ def test_scatter_with_factored_operator():
     assert float((xg.grad - xr.grad).abs().max() / xr.grad.abs().max()) <= 2e-5
 
 
-def test_factored_needs_the_register_path_and_column_dot():
-    from esc_gnn_amd import get_Batch_Wjxs, synthetic
+def test_factored_large_graph_multi_launch_and_column_dot(monkeypatch):
+    """graphs beyond one workgroup (1000 nodes; and a relabelled 20 000-node cloud): the multi-launch step kernels
+    with one value per channel, rotations as separate launches, forward and backward vs the BSR-3 chain."""
+    from esc_gnn_amd import get_Batch_Wjxs, synthetic, ScatterOperator, FactoredVectorOperator
     from esc_gnn_amd.process_pyg_data import build_PQ_batch
     pos = torch.from_numpy(synthetic.ellipsoid_clouds(1, 1000, seed=1).reshape(-1, 3)).to(DEV)
     gp = torch.tensor([0, 1000], dtype=torch.int32, device=DEV)
     b = build_PQ_batch(pos, gp, 8, {"kernel": "gaussian", "gaussian_eps": 0.05}, factored=True)
-    with pytest.raises(NotImplementedError):                      # a 1000-node graph is beyond one workgroup's 512 rows
-        get_Batch_Wjxs(pos.reshape(-1, 1), b["Q_factored"], J=2)
+    assert not b["Q_factored"].fits_register_path(4)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    xa = torch.randn(3000, 1, device=DEV, generator=g).requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    Wf, Wq = get_Batch_Wjxs(xa, b["Q_factored"], J=3), get_Batch_Wjxs(xb, b["Q"], J=3)
+    assert _rel(Wf, Wq) <= 1e-5
+    G = torch.randn(Wq.shape, device=DEV, generator=g)
+    (Wf * G).sum().backward(); (Wq * G).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max() / xb.grad.abs().max()) <= 1e-5
+    # one big cloud, rows relabelled for locality (ESCAT_REORDER=1 forces it at this size)
+    monkeypatch.setenv("ESCAT_REORDER", "1")
+    c = synthetic.single_cloud(20000, 12, workers=1)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    none = (torch.zeros(1, dtype=torch.int32, device=DEV), 0, 0)
+    opQ = ScatterOperator.from_bsr3(t(c["rowptr"]), t(c["col"]), t(c["blk"]), c["N"], parts=none)
+    fop = FactoredVectorOperator.from_frames(t(c["rowptr"]), t(c["col"]), t(c["pval"]), t(c["frames"]), parts=none)
+    assert fop.signed.row_perm is not None
+    xv = t(c["pos"]).reshape(-1, 1)
+    assert _rel(get_Batch_Wjxs(xv, fop, J=4), get_Batch_Wjxs(xv, opQ, J=4)) <= 1e-5
     with pytest.raises(ValueError):
         build_PQ_batch(pos, gp, 8, {"kernel": "gaussian", "gaussian_eps": 0.05}, sing_vect_align_method="procrustes", factored=True)

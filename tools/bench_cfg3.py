@@ -14,6 +14,8 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--sort-axis", type=int, default=None)
     ap.add_argument("--check", action="store_true", help="telescoping-sum property check on the result")
+    ap.add_argument("--factored", action="store_true",
+                    help="also run the vector operator in factored form (frames + signed scalar operator, 16 B per nonzero)")
     args = ap.parse_args()
     from esc_gnn_amd import synthetic
     t0 = time.time()
@@ -51,6 +53,32 @@ def main():
            "frac_of_8TBs": alg / (tf * 1e-3) / 1e9 / 8000.0, "gen_s": gen_s}
     if args.bwd:
         out.update({"bwd_ms": tb, "bwd_alg_GBs": alg / (tb * 1e-3) / 1e9})
+    if args.factored:
+        from esc_gnn_amd import FactoredVectorOperator
+        fop = FactoredVectorOperator.from_frames(t(b["rowptr"]), t(b["col"]), t(b["pval"]), t(b["frames"]),
+                                                 parts=(torch.zeros(1, dtype=torch.int32, device=dev), 0, 0))
+        if args.bwd:
+            fop.signed.csr_t()
+        tff = tfb = 0.0
+        for r in range(args.reps + 1):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            Wf = get_Batch_Wjxs(xv, fop, J=args.J)
+            e[1].record()
+            if args.bwd:
+                xv.grad = None
+                Wf.backward(g)
+            e[2].record()
+            torch.cuda.synchronize()
+            if r >= 1:
+                tff += e[0].elapsed_time(e[1]); tfb += e[1].elapsed_time(e[2])
+        tff /= args.reps; tfb /= args.reps
+        algf = T * (4 * (N + 1) + 16 * nnz) + 12 * N + 12 * N * F + 2 * 36 * N
+        out["factored"] = {"fwd_ms": tff, "fwd_ms_per_step": tff / T, "bytes_per_nonzero": 16,
+                           "fwd_alg_GBs_at_16B_per_nnz": algf / (tff * 1e-3) / 1e9,
+                           "max_rel_diff_vs_bsr3": float(((Wf.detach() - W.detach()).abs().amax(dim=(0, 1)) / W.detach().abs().amax(dim=(0, 1))).max())}
+        if args.bwd:
+            out["factored"]["bwd_ms"] = tfb
     if args.check:
         out["telescoping_max_abs_err"] = float((W.detach().sum(-1).reshape(-1) - xv.detach().reshape(-1)).abs().max())
     print(json.dumps(out))
