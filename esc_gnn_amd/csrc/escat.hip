@@ -111,7 +111,8 @@ __device__ __forceinline__ void emit_one(float *o /* &OUT[row, c, 0] */, float y
 
 // ------------------------------------------------------------------ multi-launch path: scalar CSR
 // MODE 0: y = A x.   MODE 1: forward step (emit y into OUT).   MODE 2: backward step (y += gathered G).
-// VP = 3: one value per channel, val (nnz, 3) (the signed scalar operator of a factored vector operator, see OpCsrV3).
+// VP = 3: one value per channel, val (nnz, 3) (the signed scalar operator of a factored vector operator, see OpCsrV3);
+// VP = 4: the same operator as |value| (nnz,) + the three signs in bits 29..31 of col (8 B per nonzero instead of 16).
 template <int C, int G, int MODE, int VP = 1>
 __global__ void __launch_bounds__(256)
 k_csr_step(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
@@ -126,12 +127,19 @@ k_csr_step(const int *__restrict__ rowptr, const int *__restrict__ col, const fl
         for (int c = 0; c < C; ++c) acc[c] = 0.f;
         const int e1 = rowptr[row + 1];
         for (int e = rowptr[row] + lg; e < e1; e += G) {
+            if constexpr (VP == 4) {             // |value| + three sign bits in the column word (bits 29..31)
+                const unsigned cw = (unsigned)col[e], vb = __float_as_uint(val[e]);
+                const float *x = xin + (int64_t)(cw & 0x1fffffffu) * ldx;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += __uint_as_float(vb | ((cw << (2 - c)) & 0x80000000u)) * x[c];
+                continue;
+            }
             const float *x = xin + (int64_t)col[e] * ldx;
             if constexpr (VP == 1) {
                 const float v = val[e];
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] += v * x[c];
-            } else {
+            } else if constexpr (VP == 3) {
                 const float *v = val + (int64_t)e * VP;
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] += v[c] * x[c];
@@ -740,7 +748,7 @@ template <int CC, int DMAX> struct OpCsr {
 // process_pyg_data's column_dot alignment builds, process_pyg_data.py:306-313, :492), so Q^t = D Pt^t D^T and the chain
 // runs in the local frames on P's pattern with 12 B of values per nonzero instead of 36.  Same LDS layout and gathers
 // as OpCsr<3>; pack layout val[((doff_s + d) * 3 + c) * 64 + lane] (escat_sell.val_planes = 3).
-template <int DMAX> struct OpCsrV3 {
+template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
     static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
     static constexpr int C = 3, CP = 4;
     static constexpr int MINW = 4;                // <= 128 VGPRs (60 of them values): two 512-thread workgroups per CU
@@ -753,15 +761,28 @@ template <int DMAX> struct OpCsrV3 {
         const int wl = w > 0 ? w - 1 : 0;
         const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) {
-            const float *p = sd.val + (int64_t)(doff + (d < wl ? d : wl)) * 192 + lane;
-            v[d][0] = p[0]; v[d][1] = p[64]; v[d][2] = p[128];
-        }
-#pragma unroll
         for (int j2 = 0; j2 < DMAX / 2; ++j2)
             lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
+        if constexpr (!SIGNED) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const float *p = sd.val + (int64_t)(doff + (d < wl ? d : wl)) * 192 + lane;
+                v[d][0] = p[0]; v[d][1] = p[64]; v[d][2] = p[128];
+            }
+        } else {          // one plane of magnitudes from HBM; the signs ride in bits 11..13 of the slot's LDS-row field
+            float m[DMAX];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) m[d] = sd.val[(int64_t)(doff + (d < wl ? d : wl)) * 64 + lane];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const unsigned f = field(d), mb = __float_as_uint(m[d]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[d][c] = __uint_as_float(mb | ((f << (20 - c)) & 0x80000000u));
+            }
+        }
     }
-    __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    __device__ __forceinline__ unsigned field(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    __device__ __forceinline__ unsigned row_of(int d) const { return SIGNED ? (field(d) & 0x7ffu) : field(d); }
     template <int W>
     __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[3]) const
     {
@@ -790,9 +811,16 @@ template <int DMAX> struct OpCsrV3 {
                                                 int gs, const float *xa, float (&acc)[3])
     {
         for (int e = e0; e < e0 + n; ++e) {
-            const float *x = xa + (col[e] - gs) * 4;
+            if constexpr (SIGNED) {          // global arrays in the packed form of k_csr_step<.., 4>
+                const unsigned cw = (unsigned)col[e], vb = __float_as_uint(val[e]);
+                const float *x = xa + ((int)(cw & 0x1fffffffu) - gs) * 4;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = fmaf(val[(int64_t)e * 3 + c], x[c], acc[c]);
+                for (int c = 0; c < 3; ++c) acc[c] = fmaf(__uint_as_float(vb | ((cw << (2 - c)) & 0x80000000u)), x[c], acc[c]);
+            } else {
+                const float *x = xa + (col[e] - gs) * 4;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = fmaf(val[(int64_t)e * 3 + c], x[c], acc[c]);
+            }
         }
     }
 };
@@ -1293,11 +1321,12 @@ static int launch_csr_step(int C, int G, const int *rp, const int *ci, const flo
                            float *y, int ldy, int64_t n, const StepEv &ev, float *OUT, int64_t ld_row, int F, hipStream_t st,
                            int planes = 1)
 {
-    if (planes == 3) {
-        if (C != 3) return fail(ESCAT_EINVAL, "one value per channel (val_planes = 3) needs C = 3, got %d", C);
-        if (G == 4)      hipLaunchKernelGGL((k_csr_step<3, 4, MODE, 3>), dim3(grid_for(n, 64)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
-        else if (G == 8) hipLaunchKernelGGL((k_csr_step<3, 8, MODE, 3>), dim3(grid_for(n, 32)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
-        else             hipLaunchKernelGGL((k_csr_step<3, 16, MODE, 3>), dim3(grid_for(n, 16)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
+    if (planes == 3 || planes == 4) {
+        if (C != 3) return fail(ESCAT_EINVAL, "one value per channel (val_planes = 3, 4) needs C = 3, got %d", C);
+#define GO(GG, VV, RPB) hipLaunchKernelGGL((k_csr_step<3, GG, MODE, VV>), dim3(grid_for(n, RPB)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F)
+        if (planes == 3) { if (G == 4) GO(4, 3, 64); else if (G == 8) GO(8, 3, 32); else GO(16, 3, 16); }
+        else             { if (G == 4) GO(4, 4, 64); else if (G == 8) GO(8, 4, 32); else GO(16, 4, 16); }
+#undef GO
         return ESCAT_OK;
     }
     switch (C) {
@@ -1423,11 +1452,11 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
     sd->part_list = sell->part_list; sd->part_row0 = sell->part_row0;
     if (sell->orders < 0 || sell->orders > 2) return fail(ESCAT_EINVAL, "escat_sell.orders=%d: 0, 1 or 2", sell->orders);
     sd->orders = sell->orders;
-    if (sell->val_planes != 0 && sell->val_planes != 1 && sell->val_planes != 3)
-        return fail(ESCAT_EINVAL, "escat_sell.val_planes=%d: 0/1 (one value per entry) or 3 (one per channel)", sell->val_planes);
-    sd->planes = sell->val_planes == 3 ? 3 : 1;
+    if (sell->val_planes != 0 && sell->val_planes != 1 && sell->val_planes != 3 && sell->val_planes != 4)
+        return fail(ESCAT_EINVAL, "escat_sell.val_planes=%d: 0/1 (one value per entry), 3 (one per channel) or 4 (|value| + sign bits)", sell->val_planes);
+    sd->planes = sell->val_planes >= 3 ? sell->val_planes : 1;
     sd->frames = sell->frames;
-    if (sd->frames && sd->planes != 3) return fail(ESCAT_EINVAL, "escat_sell.frames goes with val_planes = 3");
+    if (sd->frames && sd->planes < 3) return fail(ESCAT_EINVAL, "escat_sell.frames goes with val_planes = 3");
     if (sd->frames && sd->orders) return fail(ESCAT_EINVAL, "escat_sell.frames and .orders exclude each other");
     return ESCAT_OK;
 }
@@ -1537,6 +1566,10 @@ template <int DMAX, bool BWD>
 static int launch_csrv3_sell_d(int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd, const float *IN,
                                float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
+    if (sd.planes == 4) {
+        if (max_rows <= 256) return launch_sell_k<OpCsrV3<DMAX, true>, 256, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+        return launch_sell_k<OpCsrV3<DMAX, true>, 512, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+    }
     if (max_rows <= 256) return launch_sell_k<OpCsrV3<DMAX>, 256, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
     return launch_sell_k<OpCsrV3<DMAX>, 512, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
 }
@@ -1544,8 +1577,8 @@ template <bool BWD>
 static int launch_csr_sell(int C, int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd,
                            const float *IN, float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
-    if (sd.planes == 3) {
-        if (C != 3) return fail(ESCAT_EINVAL, "a pack with one value per channel (val_planes = 3) needs C = 3, got %d", C);
+    if (sd.planes >= 3) {
+        if (C != 3) return fail(ESCAT_EINVAL, "a pack with one value per channel (val_planes = 3, 4) needs C = 3, got %d", C);
         switch (sd.dmax) {
             case 8:  return launch_csrv3_sell_d<8, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
             case 16: return launch_csrv3_sell_d<16, BWD>(max_rows, ci, v, n_parts, sd, IN, RES, T, tab, F, st);
@@ -1582,9 +1615,9 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
     const int force = chain_path_override();
     // one value per channel: val is (nnz, 3).  Runs on the register-resident path (packed) or the multi-launch path (a
     // descriptor-only escat_sell: val = NULL, val_planes = 3); the LDS-streaming lane-group kernel has no such form.
-    const int planes = sell && sell->val_planes == 3 ? 3 : 1;
+    const int planes = sell && sell->val_planes >= 3 ? sell->val_planes : 1;
     const bool packed = sell && sell->val != nullptr;
-    if (planes == 3 && C != 3) return fail(ESCAT_EINVAL, "one value per channel (val_planes = 3) needs C = 3, got %d", C);
+    if (planes >= 3 && C != 3) return fail(ESCAT_EINVAL, "one value per channel (val_planes = 3, 4) needs C = 3, got %d", C);
     if (sell && !packed && (sell->part_list || sell->orders || sell->frames)) return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
     if (part_ptr && n_parts > 0 && max_part_rows > 0 && force < 3 && (planes == 1 || packed)) {
         const size_t lds = (size_t)max_part_rows * C * (2 + F) * sizeof(float);
@@ -1597,7 +1630,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
                 if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
                 rc = launch_csr_sell<BWD>(C, max_part_rows, col, val, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
-            } else if (sell && (sell->part_list || sell->orders || sell->val_planes == 3))
+            } else if (sell && (sell->part_list || sell->orders || sell->val_planes >= 3))
                 return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
             else
                 rc = launch_chain_csr<BWD>(C, G, rowptr, col, val, part_ptr, n_parts, lds, IN, RES, T, tab, F, st);

@@ -17,7 +17,6 @@ operator and cached on the tensor object); the products themselves never touch
 torch.
 """
 import os
-import os
 from typing import Optional
 import numpy as np
 import torch
@@ -170,7 +169,8 @@ class Sell:
         V = 9 if form.val.dim() == 3 else (3 if form.val.dim() == 2 else 1)
         if V == 3 and form.val.shape[1] != 3:
             raise ValueError("escat: per-channel CSR values must be (nnz, 3)")
-        self.val_planes = V if V == 3 else 1
+        signed = form.signed_pack() if V == 3 else None
+        self.val_planes = (4 if signed is not None else 3) if V == 3 else 1
         caps = _SELL_DMAX[V]
         deg_all = (form.rowptr[1:] - form.rowptr[:-1]).long()
         hist = torch.bincount(deg_all.clamp(max=caps[-1] + 1), minlength=caps[-1] + 2).cumsum(0)
@@ -227,6 +227,9 @@ class Sell:
             for sp, q in enumerate(_BSR3_PIECE_ORDER):      # stored position sp holds block entry q (row-major)
                 dst = drow * 576 + (sp // 4) * 256 + (lane * 4 + sp % 4 if sp < 8 else lane)
                 val[dst] = src[:, q]
+        elif V == 3 and signed is not None:          # one plane of magnitudes; the signs go beside the LDS rows below
+            val = torch.zeros((total_d + 1) * 64, dtype=torch.float32, device=dev)
+            val[drow * 64 + lane] = signed[1][e_k]
         elif V == 3:
             val = torch.zeros((total_d + 1) * 192, dtype=torch.float32, device=dev)
             src = form.val[e_k]
@@ -240,6 +243,10 @@ class Sell:
         slice_of_drow = torch.repeat_interleave(torch.arange(n_slices, device=dev), w)
         lcu = zc[slice_of_drow].repeat_interleave(64)                                     # (total_d*64,)
         lcu[drow * 64 + lane] = lc_of_e[e_k].long()
+        if V == 3 and signed is not None:
+            if int(lc_of_e.max() if nnz else 0) >= (1 << 11):
+                raise ValueError("escat: LDS row index does not leave room for the sign bits")
+            lcu[drow * 64 + lane] |= signed[2][e_k].long() << 11
         npair = ((w + 3) // 4) * 2
         slice_of_pair = torch.repeat_interleave(torch.arange(n_slices, device=dev), npair)
         j2 = torch.arange(total_p, device=dev) - poff[slice_of_pair]
@@ -323,7 +330,8 @@ class SellGlobal:
 
 
 class _Csr:
-    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "max_row_nnz", "_sell", "_sell_g")
+    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "max_row_nnz", "_sell", "_sell_g",
+                 "_signed")
 
     def __init__(self, rowptr, col, val, n, parts=None):
         self.rowptr, self.col, self.val, self.n = rowptr, col, val, n
@@ -334,6 +342,22 @@ class _Csr:
         self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) if n > 0 else 0
         self._sell = None
         self._sell_g = None
+        self._signed = None
+
+    def signed_pack(self):
+        """per-channel values (nnz, 3) that differ in sign only (the signed operator of a factored vector operator):
+        (col | signs << 29, |value|) -- 8 B per nonzero for the kernels (escat_sell.val_planes = 4).  None otherwise
+        (then the three planes are used as they are, val_planes = 3), or with ESCAT_FACTORED_FORMAT=planes."""
+        if self._signed is None:
+            self._signed = False
+            if self.val.dim() == 2 and self.val.shape[1] == 3 and self.n < (1 << 29) \
+                    and os.environ.get("ESCAT_FACTORED_FORMAT", "") != "planes":
+                mag = self.val.abs()
+                if self.nnz == 0 or bool((mag == mag[:, :1]).all()):
+                    neg = (torch.signbit(self.val) & (mag > 0)).to(torch.int32)
+                    bits = neg[:, 0] | (neg[:, 1] << 1) | (neg[:, 2] << 2)
+                    self._signed = ((self.col | (bits << 29)).contiguous(), mag[:, 0].contiguous(), bits)
+        return self._signed or None
 
     def sell_global(self):
         """whole-operator pack with global columns for the multi-launch path (BSR-3 only)."""

@@ -111,9 +111,12 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
                                      sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif per_channel_vals:
-        # no pack (graphs too large for the register path): a descriptor that only says "val is (nnz, 3)"
-        sell_struct = _lib.EscatSell(0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0)
+        # no pack (graphs too large for the register path): a descriptor that only says how val / col are laid out
+        sell_struct = _lib.EscatSell(0, 0, 0, 0, 0, 0, 4 if form.signed_pack() is not None else 3, 0, 0, 0, 0, 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
+    col_t, val_t = form.col, form.val
+    if per_channel_vals and (sell.val_planes == 4 if sell is not None else form.signed_pack() is not None):
+        col_t, val_t = form.signed_pack()[0], form.signed_pack()[1]      # column | signs << 29, |value|
     with torch.cuda.device(dev):
         st = _stream(dev)
         if use_bsr:
@@ -123,7 +126,7 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
                     _ptr(form.part_ptr), form.n_parts, form.max_part_rows, sell_ref, _ptr(ws), ws_bytes, st)
         else:
             fn = lib.escat_chain_csr_bwd_f32 if backward else lib.escat_chain_csr_f32
-            rc = fn(_ptr(form.rowptr), _ptr(form.col), _ptr(form.val), form.n, form.nnz, _ptr(inp), C, T,
+            rc = fn(_ptr(form.rowptr), _ptr(col_t), _ptr(val_t), form.n, form.nnz, _ptr(inp), C, T,
                     ctypes.cast(ev, ctypes.c_void_p), len(plan_events), F, _ptr(out),
                     _ptr(form.part_ptr), form.n_parts, form.max_part_rows, sell_ref, _ptr(ws), ws_bytes, st)
     _lib.check(rc, fn.__name__ if hasattr(fn, "__name__") else "escat chain")

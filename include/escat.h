@@ -91,7 +91,12 @@ typedef struct {
     int32_t         n_slices;
     int32_t         slices_per_part;
     int32_t         val_planes;     /* CSR packs: 0/1 = one value per entry; 3 = one value per channel (C = 3):
-                                     * val[((doff_s + d)*3 + c)*64 + lane], and the entry points' `val` is (nnz, 3) */
+                                     * val[((doff_s + d)*3 + c)*64 + lane], and the entry points' `val` is (nnz, 3);
+                                     * 4 = the same operator when the three values differ in sign only: one plane of
+                                     * |value| as for 1, the signs of channels 0..2 in bits 11..13 of each 16-bit LDS-row
+                                     * field of lc, and -- in the entry points' global arrays -- `val` (nnz,) = |value|,
+                                     * `col` = column | signs << 29.  A struct with val = NULL and val_planes = 3 or 4
+                                     * only describes the global arrays (multi-launch path, no pack). */
     /* whole-operator variant for the multi-launch path of graphs that do not fit LDS (BSR-3 only), selected by
      * col32 != NULL: slices of 64 rows sorted by length inside windows, no dmax cap; val as above,
      * col32[(doff_s + d)*64 + lane] = GLOBAL block column (-1 = padding), perm[s*64 + lane] = global row (-1: none),

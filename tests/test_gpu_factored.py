@@ -39,16 +39,24 @@ def test_rotation_kernel():
         assert (rotate_frames(O, rotate_frames(O, X, True), False) - X).abs().max() < 1e-5   # O O^T = I
 
 
+@pytest.mark.parametrize("values", ["signs", "general"])
 @pytest.mark.parametrize("B,n,k", [(64, 128, 5), (40, 500, 10), (12, 300, 30), (50, 7, 3)])
-def test_per_channel_csr_chain(B, n, k):
-    """y[i][c] = sum_j v[i,j][c] x[j][c]: the 3-plane pack == three single-channel chains, forward and backward
-    (k = 30: rows longer than the pack's 24 slots -> tails; n = 7: many tiny graphs per workgroup)."""
+def test_per_channel_csr_chain(B, n, k, values):
+    """y[i][c] = sum_j v[i,j][c] x[j][c]: the per-channel pack == three single-channel chains, forward and backward
+    (k = 30: rows longer than the pack's 24 slots -> tails; n = 7: many tiny graphs per workgroup).
+    values = signs: the three values differ in sign only -> |value| + sign bits (val_planes = 4);
+    general: unrelated values -> three planes (val_planes = 3)."""
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator
     pos, b = _built(B, n, k, seed=n + k, factored=False)
     N = B * n
     g = torch.Generator(device=DEV).manual_seed(1)
-    val3 = (b["pval"][:, None] * torch.where(torch.rand(b["nnz"], 3, device=DEV, generator=g) < 0.4, -1.0, 1.0)).contiguous()
+    val3 = b["pval"][:, None] * torch.where(torch.rand(b["nnz"], 3, device=DEV, generator=g) < 0.4, -1.0, 1.0)
+    if values == "general":
+        val3 = val3 * (0.5 + torch.rand(b["nnz"], 3, device=DEV, generator=g))
+    val3 = val3.contiguous()
     op3 = ScatterOperator.from_csr(b["rowptr"], b["col"], val3, N, validate=False)
+    assert (op3.csr().signed_pack() is not None) == (values == "signs")
+    assert op3.csr().sell().val_planes == (4 if values == "signs" else 3)
     x = torch.randn(N, 3, device=DEV, generator=g)
     for kw in (dict(J=4), dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16]))):
         xg = x.clone().requires_grad_(True)
@@ -66,13 +74,14 @@ def test_per_channel_csr_chain(B, n, k):
         get_Batch_Wjxs(x[:, :2].contiguous(), op3, J=2)            # one value per channel: C must be 3
 
 
-@pytest.mark.parametrize("rotate", ["fused", "separate"])
-@pytest.mark.parametrize("B,n,k,J", [(256, 128, 5, 4), (128, 500, 10, 4), (16, 500, 16, 6), (700, 37, 4, 3)])
-def test_factored_chain_vs_bsr3(B, n, k, J, rotate, monkeypatch):
+@pytest.mark.parametrize("rotate,fmt", [("fused", "signed"), ("separate", "signed"), ("fused", "planes")])
+@pytest.mark.parametrize("B,n,k,J", [(256, 128, 5, 4), (128, 500, 10, 4), (16, 500, 16, 6), (700, 37, 4, 3), (10, 400, 30, 3)])
+def test_factored_chain_vs_bsr3(B, n, k, J, rotate, fmt, monkeypatch):
     """rotate: inside the chain kernel (escat_sell.frames, the default) or as two escat_rotate_frames_f32 launches.
     700 graphs: more parts than resident workgroups, so the pipelined prologue / epilogue of both directions runs."""
     from esc_gnn_amd import get_Batch_Wjxs
     monkeypatch.setenv("ESCAT_FACTORED_ROTATE", rotate)
+    monkeypatch.setenv("ESCAT_FACTORED_FORMAT", fmt)            # |value| + sign bits (default) / three value planes
     pos, b = _built(B, n, k, seed=3 * n + k)
     Qf, Q = b["Q_factored"], b["Q"]
     # the factors reproduce the builder's blocks
@@ -109,11 +118,13 @@ def test_scatter_with_factored_operator():
     assert float((xg.grad - xr.grad).abs().max() / xr.grad.abs().max()) <= 2e-5
 
 
-def test_factored_large_graph_multi_launch_and_column_dot(monkeypatch):
+@pytest.mark.parametrize("fmt", ["signed", "planes"])
+def test_factored_large_graph_multi_launch_and_column_dot(monkeypatch, fmt):
     """graphs beyond one workgroup (1000 nodes; and a relabelled 20 000-node cloud): the multi-launch step kernels
     with one value per channel, rotations as separate launches, forward and backward vs the BSR-3 chain."""
     from esc_gnn_amd import get_Batch_Wjxs, synthetic, ScatterOperator, FactoredVectorOperator
     from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    monkeypatch.setenv("ESCAT_FACTORED_FORMAT", fmt)
     pos = torch.from_numpy(synthetic.ellipsoid_clouds(1, 1000, seed=1).reshape(-1, 3)).to(DEV)
     gp = torch.tensor([0, 1000], dtype=torch.int32, device=DEV)
     b = build_PQ_batch(pos, gp, 8, {"kernel": "gaussian", "gaussian_eps": 0.05}, factored=True)
