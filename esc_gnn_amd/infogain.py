@@ -26,7 +26,7 @@ from typing import Dict, Iterable, Optional, Tuple
 import torch
 
 from . import _lib
-from .pyg_utilities import _run_chain, _ptr, _stream
+from .pyg_utilities import bank, _ptr, _stream
 from .operators import as_operator
 from .scales import ChainPlan
 
@@ -51,7 +51,8 @@ def diffusion_powers(x: torch.Tensor, P_sparse, T: int) -> torch.Tensor:
     op = as_operator(P_sparse)
     if op.n != x.shape[0]:
         raise RuntimeError(f"escat: size mismatch, operator is {op.n}x{op.n} but x has {x.shape[0]} rows")
-    return _run_chain(op, all_powers_plan(int(T)), x, backward=False)
+    with torch.no_grad():
+        return bank(x, op, all_powers_plan(int(T)))
 
 
 def divergence_by_graph(Ptxs: torch.Tensor, graph_ptr: torch.Tensor, Ptx_i_start: int = 2, divergence_metric: str = "kl",

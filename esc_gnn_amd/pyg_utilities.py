@@ -210,6 +210,21 @@ def rotate_frames(frames: torch.Tensor, X: torch.Tensor, transpose: bool) -> tor
     return _RotateFrames.apply(frames, X, transpose)
 
 
+def bank(x: torch.Tensor, op, plan: ChainPlan) -> torch.Tensor:
+    """(rows, C) -> (rows, C, F) for a chain plan on a canonical operator (differentiable w.r.t. x)."""
+    if isinstance(op, FactoredVectorOperator):
+        if x.shape[1] != 1:
+            raise ValueError("escat: the factored vector operator takes the flattened vector feature (3N, 1)")
+        # Q^t = D Pt^t D^T: into the local frames, the chain on the signed scalar operator, every band back out --
+        # all inside the chain kernel (escat_sell.frames) when the graphs fit the register-resident path; otherwise
+        # (or with ESCAT_FACTORED_ROTATE=separate) two rotation launches around the chain
+        if os.environ.get("ESCAT_FACTORED_ROTATE", "") == "separate" or not op.fits_register_path(plan.F):
+            u = rotate_frames(op.frames, x.view(-1, 3, 1), transpose=True).view(-1, 3)
+            return rotate_frames(op.frames, _WaveletBank.apply(u, op.signed, plan), transpose=False).view(x.shape[0], 1, -1)
+        return _FactoredBank.apply(x.view(-1, 3), op, plan).view(x.shape[0], 1, -1)
+    return _WaveletBank.apply(x, op, plan)
+
+
 def get_Batch_Wjxs(
     x: torch.Tensor,
     P_sparse,
@@ -244,18 +259,7 @@ def get_Batch_Wjxs(
         raise RuntimeError(f"escat: size mismatch, operator is {op.n}x{op.n} but x has {x.shape[0]} rows")
     if plan.per_channel and plan.n_channels != x.shape[1]:
         raise IndexError("index out of range: per-channel diffusion_scales rows != channels of x")
-    if isinstance(op, FactoredVectorOperator):
-        if x.shape[1] != 1:
-            raise ValueError("escat: the factored vector operator takes the flattened vector feature (3N, 1)")
-        # Q^t = D Pt^t D^T: into the local frames, the chain on the signed scalar operator, every band back out --
-        # all inside the chain kernel (escat_sell.frames); ESCAT_FACTORED_ROTATE=separate keeps the two rotation launches
-        if os.environ.get("ESCAT_FACTORED_ROTATE", "") == "separate" or not op.fits_register_path(plan.F):
-            u = rotate_frames(op.frames, x.view(-1, 3, 1), transpose=True).view(-1, 3)
-            W = rotate_frames(op.frames, _WaveletBank.apply(u, op.signed, plan), transpose=False).view(x.shape[0], 1, -1)
-        else:
-            W = _FactoredBank.apply(x.view(-1, 3), op, plan).view(x.shape[0], 1, -1)
-    else:
-        W = _WaveletBank.apply(x, op, plan)
+    W = bank(x, op, plan)
     if not plan.per_channel and plan.T >= 0 and filter_stack_dim not in (-1, 2) \
             and not (diffusion_scales is None and scales_type is None):
         W = W.movedim(-1, filter_stack_dim)

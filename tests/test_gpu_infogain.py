@@ -253,3 +253,22 @@ def test_full_size_properties():
         rows = (perm[:, None] * (n * d) + torch.arange(n * d, device=DEV)[None]).reshape(-1)
         sub = divergence_by_graph(W[rows].contiguous(), torch.arange(513, dtype=torch.int32, device=DEV) * (n * d), 2, "kl", None)
         assert torch.equal(sub, div[perm])
+
+
+def test_vector_track_with_the_factored_operator():
+    """the vector operator in factored form (FactoredVectorOperator) feeds the same fit: powers within the chain's 1e-5,
+    divergences (fixed floor: no near-tie sensitivity) within 1e-4 of the BSR-3 route."""
+    from esc_gnn_amd import synthetic
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    from esc_gnn_amd.infogain import diffusion_powers, divergence_by_graph
+    B, n = 64, 200
+    pos = torch.from_numpy(synthetic.ellipsoid_clouds(B, n, seed=8).reshape(-1, 3)).to(DEV)
+    gp = torch.arange(B + 1, dtype=torch.int32, device=DEV) * n
+    b = build_PQ_batch(pos, gp, 6, {"kernel": "gaussian", "gaussian_eps": 0.05}, factored=True)
+    Wq = diffusion_powers(pos.reshape(-1, 1), b["Q"], 16)
+    Wf = diffusion_powers(pos.reshape(-1, 1), b["Q_factored"], 16)
+    assert Wf.shape == Wq.shape == (3 * B * n, 1, 17)
+    assert (Wf - Wq).abs().max() <= 1e-5 * Wq.abs().max()
+    dq = divergence_by_graph(Wq, gp * 3, 2, "kl", 1e-2)
+    df = divergence_by_graph(Wf, gp * 3, 2, "kl", 1e-2)
+    assert (df - dq).abs().max() <= 1e-4 * dq.abs().max() + 1e-6
