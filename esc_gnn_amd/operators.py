@@ -701,8 +701,9 @@ class FactoredVectorOperator:
     frames (N, 3, 3): columns are the frame vectors O_i[:, c];  signed: ScatterOperator over N rows, val (nnz, 3).
     """
 
-    def __init__(self, frames: torch.Tensor, signed: "ScatterOperator"):
-        if frames.dim() != 3 or frames.shape[1:] != (3, 3) or frames.shape[0] != signed.n:
+    def __init__(self, frames: torch.Tensor, signed):
+        base = signed.base if isinstance(signed, OperatorBatch) else signed
+        if frames.dim() != 3 or frames.shape[1:] != (3, 3) or frames.shape[0] != base.n:
             raise ValueError("escat: frames must be (N, 3, 3) with N = rows of the signed operator")
         self.frames = frames.to(torch.float32).contiguous()
         self.signed = signed
@@ -710,12 +711,25 @@ class FactoredVectorOperator:
         self.device = frames.device
         self.row_perm = None
 
+    def select(self, part_ids) -> "FactoredVectorOperator":
+        """mini-batch of parts (samples of a store) as a view, like ScatterOperator.select; the frames stay whole (the
+        kernel indexes them by the operator's own rows)."""
+        if isinstance(self.signed, OperatorBatch):
+            raise ValueError("escat: select() applies to a stored operator, not to a view of one")
+        return FactoredVectorOperator(self.frames, self.signed.select(part_ids))
+
+    def row_index(self) -> torch.Tensor:
+        """scalar rows (3 per node) of the stored operator that a view covers, in view order (to gather x)."""
+        ri = self.signed.row_index() if isinstance(self.signed, OperatorBatch) else torch.arange(self.signed.n, device=self.device)
+        return (3 * ri[:, None] + torch.arange(3, device=ri.device)[None, :]).reshape(-1)
+
     def fits_register_path(self, F: int) -> bool:
         """True: one launch with the rotations inside the chain kernel; False (graphs too large for a workgroup): the
         rotations are two escat_rotate_frames_f32 launches around the multi-launch chain."""
         from .pyg_utilities import chain_lds_bytes, LDS_BUDGET
-        form = self.signed.csr()
-        return (self.signed.row_perm is None and form.n_parts > 0 and form.sell() is not None
+        base = self.signed.base if isinstance(self.signed, OperatorBatch) else self.signed
+        form = base.csr()
+        return (base.row_perm is None and form.n_parts > 0 and form.sell() is not None
                 and max(chain_lds_bytes(form.max_part_rows, 3, F, False, False), chain_lds_bytes(form.max_part_rows, 3, F, False, True)) <= LDS_BUDGET)
 
     @staticmethod

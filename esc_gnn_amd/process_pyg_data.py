@@ -234,11 +234,13 @@ def process_pyg_data(
 
 def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k: int,
                        local_pca_kernel_fn_kwargs: Dict[str, Any], hdf5_tensor_dtype: str = "float16",
-                       chunk_graphs: int = 16384, **build_kwargs) -> Dict[str, Any]:
+                       chunk_graphs: int = 16384, store_frames: bool = False, **build_kwargs) -> Dict[str, Any]:
     """
     The P/Q -> HDF5 loop of scripts/python/generate_ellipsoid_dataset.py:1165-1213 for a whole dataset: graphs are
     built on the GPU in chunks (build_PQ_batch), the per-graph COO arrays of the reference layout are formed on the
     GPU for the whole chunk, copied to the host once and written by esc_gnn_amd.hdf5_min (atomic rename at the end).
+    store_frames=True adds /frames/{idx}/values, the (n, 3, 3) fp32 local frames -- an extension of the layout (the
+    reference's reader never looks at it) that lets esc_gnn_amd.store load the vector operator in factored form.
     """
     import numpy as np
     from .hdf5_min import H5Writer
@@ -268,6 +270,7 @@ def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k:
             Q_r = ((3 * lrow)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1).cpu().numpy()
             Q_c = ((3 * lcol)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1).cpu().numpy()
             gpn = gp.numpy()
+            fr = b["frames"].cpu().numpy() if store_frames else None
             for g in range(g1 - g0):
                 e0, e1 = int(eoff[g]), int(eoff[g + 1])
                 ng = int(gpn[g + 1] - gpn[g])
@@ -278,4 +281,6 @@ def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k:
                 f.write(f"Q/{idx}/indices", np.stack([Q_r[9 * e0:9 * e1], Q_c[9 * e0:9 * e1]]))
                 f.write(f"Q/{idx}/values", Q_val[9 * e0:9 * e1])
                 f.write(f"Q/{idx}/size", np.array([3 * ng, 3 * ng], dtype=np.int64))
+                if store_frames:
+                    f.write(f"frames/{idx}/values", fr[int(gpn[g]):int(gpn[g + 1])])
     return {"graphs": B, "nnz": total_nnz, "path": path}

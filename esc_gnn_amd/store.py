@@ -8,16 +8,21 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 import torch
 
-from .operators import ScatterOperator
+from .operators import ScatterOperator, FactoredVectorOperator
 
 
-def load_operator_store(path: str, device, indices: Optional[Sequence[int]] = None, pack: bool = True) -> Dict:
+def load_operator_store(path: str, device, indices: Optional[Sequence[int]] = None, pack: bool = True,
+                        factored: bool = False) -> Dict:
     """
     Reads the reference's HDF5 operator layout (/{P,Q}/{idx}/{indices,values,size},
     scripts/python/generate_ellipsoid_dataset.py:1185-1206) for the samples `indices` (default: all, in numeric order)
     and returns {"P": ScatterOperator, "Q": ScatterOperator, "graph_ptr": int64 (B+1,) node offsets, "ids": list}.
     Values stored as fp16 are widened to fp32 as the reference loader does (escgnn_data_classes.py:137-142).
     The operators carry one part per sample; with pack=True the SELL packs of all four forms are built now.
+    factored=True (files written with store_frames=True, esc_gnn_amd.process_pyg_data.write_dataset_hdf5) also returns
+    "Q_factored": the vector operator as frames + signed scalar operator built from P's stored values.  It equals the
+    stored Q to fp32 rounding only if the file holds fp32 values: fp16 storage rounds every Q entry on its own, which no
+    factorisation reproduces (the factored operator is then the closer one to the operator before rounding).
     """
     from .hdf5_min import H5Reader
     f = H5Reader(path)
@@ -45,6 +50,16 @@ def load_operator_store(path: str, device, indices: Optional[Sequence[int]] = No
                 for form in forms:
                     form.sell()
             out[key] = op
+        if factored:
+            if "frames" not in f.keys():
+                raise KeyError("escat: this file has no /frames group (write it with store_frames=True)")
+            frames = np.concatenate([np.asarray(f["frames"][str(i)]["values"][...], dtype=np.float32) for i in ids])
+            pc = out["P"].csr()
+            out["Q_factored"] = FactoredVectorOperator.from_frames(
+                pc.rowptr, pc.col, pc.val, torch.from_numpy(frames).to(device),
+                parts=ScatterOperator.parts_from_graph_ptr(torch.from_numpy(gp).to(device)))
+            if pack:
+                out["Q_factored"].signed.csr().sell(); out["Q_factored"].signed.csr_t().sell()
         out["graph_ptr"] = torch.from_numpy(gp).to(device)
         out["ids"] = ids
         return out

@@ -149,3 +149,43 @@ def test_factored_large_graph_multi_launch_and_column_dot(monkeypatch, fmt):
     assert _rel(get_Batch_Wjxs(xv, fop, J=4), get_Batch_Wjxs(xv, opQ, J=4)) <= 1e-5
     with pytest.raises(ValueError):
         build_PQ_batch(pos, gp, 8, {"kernel": "gaussian", "gaussian_eps": 0.05}, sing_vect_align_method="procrustes", factored=True)
+
+
+def test_store_with_frames_and_factored_views(tmp_path):
+    """dataset -> HDF5 (reference layout + the /frames extension, fp32 values) -> operator store -> shuffled
+    mini-batches as views: the factored views give what the BSR-3 views give; the file still reads as the
+    reference's layout (P, Q groups untouched)."""
+    from esc_gnn_amd import get_Batch_Wjxs, synthetic
+    from esc_gnn_amd.process_pyg_data import write_dataset_hdf5
+    from esc_gnn_amd.store import load_operator_store
+    from esc_gnn_amd.hdf5_min import H5Reader
+    sizes = [32, 64, 48, 128, 20, 300]
+    clouds = [synthetic.ellipsoid_clouds(1, n, seed=200 + n)[0] for n in sizes]
+    pos = torch.from_numpy(np.concatenate(clouds)).to(DEV)
+    gp = torch.from_numpy(np.cumsum([0] + sizes).astype(np.int32))
+    path = str(tmp_path / "pqf.h5")
+    write_dataset_hdf5(path, pos, gp, 5, {"kernel": "gaussian", "gaussian_eps": 0.1}, hdf5_tensor_dtype="float32",
+                       chunk_graphs=4, store_frames=True)
+    f = H5Reader(path)
+    assert set(f.keys()) == {"P", "Q", "frames"} and f["frames"]["3"]["values"][...].shape == (128, 3, 3)
+    f.close()
+    store = load_operator_store(path, torch.device(DEV), factored=True)
+    Qf, Q = store["Q_factored"], store["Q"]
+    assert Qf.signed.csr().n_parts == len(sizes) and Qf.signed.csr().sell().val_planes == 4
+    xv_all = pos.reshape(-1, 1)
+    W_full = get_Batch_Wjxs(xv_all, Q, J=3)
+    assert _rel(get_Batch_Wjxs(xv_all, Qf, J=3), W_full) <= 1e-5
+    order = [5, 0, 3, 3, 1]
+    vf, vq = Qf.select(order), Q.select(order)
+    assert torch.equal(vf.row_index(), vq.row_index())
+    x = xv_all[vq.row_index()].clone().requires_grad_(True)
+    xf = x.detach().clone().requires_grad_(True)
+    Wq, Wf = get_Batch_Wjxs(x, vq, J=3), get_Batch_Wjxs(xf, vf, J=3)
+    assert _rel(Wf, Wq) <= 1e-5
+    G = torch.randn(Wq.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    (Wq * G).sum().backward(); (Wf * G).sum().backward()
+    assert float((xf.grad - x.grad).abs().max() / x.grad.abs().max()) <= 1e-5
+    with pytest.raises(KeyError):
+        path2 = str(tmp_path / "plain.h5")
+        write_dataset_hdf5(path2, pos, gp, 5, {"kernel": "gaussian", "gaussian_eps": 0.1}, chunk_graphs=4)
+        load_operator_store(path2, torch.device(DEV), factored=True)
