@@ -116,14 +116,17 @@ k_pool_bwd(const float *__restrict__ vals, const int *__restrict__ seg_ptr, int6
 // ---- fused form: cosines computed on the fly from the coefficients, nothing of size (E, W) is materialised.
 // v (N, W, D): per node and wavelet a D-vector; in-edges of node n: src[seg_ptr[n] .. seg_ptr[n+1]).
 // out (N, (1+m)*W) = [norm | mean | max | min | var | levels] (the reference's torch.cat, :504).
+// 1 / max(sqrt(n2), 1e-8) with the hardware reciprocal square root (1 ulp; the clamp of the reference's norms,
+// models/escgnn_modular.py:447-452, moves onto the squared norm).  One instruction instead of sqrt + IEEE division.
+__device__ __forceinline__ float inv_norm(float n2) { return __builtin_amdgcn_rsqf(fmaxf(n2, 1e-16f)); }
+
 template <int D>
 __device__ __forceinline__ float cos_of(const float (&a)[D], float na, const float *__restrict__ b)
 {
     float dot = 0.f, nb = 0.f;
 #pragma unroll
     for (int c = 0; c < D; ++c) { const float x = b[c]; dot = fmaf(a[c], x, dot); nb = fmaf(x, x, nb); }
-    nb = sqrtf(nb); nb = nb > 1e-8f ? nb : 1e-8f;
-    return dot / (na * nb);
+    return dot * inv_norm(nb) / na;
 }
 
 // gathers the cosines of a segment into this thread's LDS column, four edges in flight at a time (the loads of one edge
@@ -132,6 +135,7 @@ template <int D>
 __device__ __forceinline__ void gather_cosines(const float *__restrict__ v, const int *__restrict__ src, int e0, int cnt, int W, int w,
                                                const float (&a)[D], float nac, float *sv, int tid, float &sum, float &sq)
 {
+    const float inac = 1.f / nac;
     for (int i0 = 0; i0 < cnt; i0 += 4) {
         float b[4][D];
 #pragma unroll
@@ -147,8 +151,7 @@ __device__ __forceinline__ void gather_cosines(const float *__restrict__ v, cons
                 float dot = 0.f, nb = 0.f;
 #pragma unroll
                 for (int c = 0; c < D; ++c) { dot = fmaf(a[c], b[u][c], dot); nb = fmaf(b[u][c], b[u][c], nb); }
-                nb = sqrtf(nb); nb = nb > 1e-8f ? nb : 1e-8f;
-                const float x = dot / (nac * nb);
+                const float x = dot * inac * inv_norm(nb);
                 sv[(i0 + u) * POOL_NT + tid] = x; sum += x; sq += x * x;
             }
         }
@@ -239,6 +242,7 @@ k_vinv_bwd(const float *__restrict__ v, const int *__restrict__ src, const int *
         nrm = sqrtf(nrm);
         const bool a_free = nrm > 1e-8f;             // the clamp passes gradient only where it does not bind
         const float nac = a_free ? nrm : 1e-8f;
+        const float inac = 1.f / nac;
         const float *go = gout + n * (int64_t)(1 + m) * W + w;
         {
             const float gn = nrm > 0.f ? go[0] / nrm : 0.f;      // d|a|/da = a/|a| (0 at the origin)
@@ -290,12 +294,10 @@ k_vinv_bwd(const float *__restrict__ v, const int *__restrict__ src, const int *
                     float nb = 0.f, dot = 0.f;
 #pragma unroll
                     for (int c = 0; c < D; ++c) { nb = fmaf(b[u][c], b[u][c], nb); dot = fmaf(a[c], b[u][c], dot); }
-                    nb = sqrtf(nb);
-                    const bool b_free = nb > 1e-8f;
-                    const float nbc = b_free ? nb : 1e-8f;
-                    const float x = dot / (nac * nbc);
-                    const float r = gc / (nac * nbc);
-                    const float ka = a_free ? gc * x / (nac * nac) : 0.f, kb = b_free ? gc * x / (nbc * nbc) : 0.f;
+                    const bool b_free = nb > 1e-16f;
+                    const float inb = inv_norm(nb);
+                    const float r = gc * inac * inb, x = dot * inac * inb;
+                    const float ka = a_free ? gc * x * inac * inac : 0.f, kb = b_free ? gc * x * inb * inb : 0.f;
 #pragma unroll
                     for (int c = 0; c < D; ++c) {
                         da[c] += r * b[u][c] - ka * a[c];
@@ -326,7 +328,7 @@ k_vinv_bwd_src(const float *__restrict__ v, const int *__restrict__ dst, const i
         for (int c = 0; c < D; ++c) { b[c] = v[g * D + c]; nb = fmaf(b[c], b[c], nb); db[c] = 0.f; }
         nb = sqrtf(nb);
         const bool b_free = nb > 1e-8f;
-        const float nbc = b_free ? nb : 1e-8f;
+        const float inbc = 1.f / (b_free ? nb : 1e-8f);
         for (int q0 = p0; q0 < p1; q0 += 4) {
             float av[4][D], gcs[4];
 #pragma unroll
@@ -344,9 +346,9 @@ k_vinv_bwd_src(const float *__restrict__ v, const int *__restrict__ dst, const i
                 float na = 0.f, dot = 0.f;
 #pragma unroll
                 for (int c = 0; c < D; ++c) { na = fmaf(av[u][c], av[u][c], na); dot = fmaf(av[u][c], b[c], dot); }
-                na = sqrtf(na); na = na > 1e-8f ? na : 1e-8f;
-                const float x = dot / (na * nbc);
-                const float r = gc / (na * nbc), kb = b_free ? gc * x / (nbc * nbc) : 0.f;
+                const float ina = inv_norm(na);
+                const float r = gc * ina * inbc, x = dot * ina * inbc;
+                const float kb = b_free ? gc * x * inbc * inbc : 0.f;
 #pragma unroll
                 for (int c = 0; c < D; ++c) db[c] += r * av[u][c] - kb * b[c];
             }

@@ -5,11 +5,12 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--graphs", type=int, default=4096); ap.add_argument("--nodes", type=int, default=500); ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--gen-workers", type=int, default=8, help="use 1 under rocprofv3 (no fork after GPU init)")
 ap.add_argument("--W", type=int, default=22); ap.add_argument("--cpu-graphs", type=int, default=4); ap.add_argument("--reps", type=int, default=5)
 args = ap.parse_args()
 import numpy as np
 from esc_gnn_amd import synthetic
-b = synthetic.ellipsoid_batch(args.graphs, args.nodes, args.k, seed=457893, workers=8, with_q=False)
+b = synthetic.ellipsoid_batch(args.graphs, args.nodes, args.k, seed=457893, workers=args.gen_workers, with_q=False)
 import torch
 from esc_gnn_amd.invariants import get_vector_invariants
 from oracle.invariants_oracle import ref_vector_invariants
