@@ -24,6 +24,8 @@ Prints ONE JSON line (rank 0) with the contract's fields plus
                 duration inside the timed region, against 8 TB/s HBM peak.
   cpu_baseline  the CPU oracle's torch.sparse.mm restatement of the reference
                 (kind "port"), timed on a bounded sample of the same batch.
+  factored_Q_variant  (N = 1 only, after the timed region, NOT the headline) the same step with the vector operator
+                in factored form Q = D Pt D^T (esc_gnn_amd.FactoredVectorOperator).
 """
 import argparse
 import json

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--factored", action="store_true", help="vector operator in factored form (FactoredVectorOperator)")
     ap.add_argument("--amp", action="store_true", help="bf16 autocast for the (plain PyTorch) head; scattering stays fp32")
     args = ap.parse_args()
     import numpy as np, torch, torch.distributed as dist
@@ -30,7 +31,9 @@ def main():
     clouds = synthetic.ellipsoid_clouds(args.graphs, args.nodes, seed=457892 + rank)
     pos = torch.from_numpy(clouds.reshape(-1, 3)).to(dev)
     gp = torch.arange(args.graphs + 1, dtype=torch.int32, device=dev) * args.nodes
-    b = build_PQ_batch(pos, gp, args.k, {"kernel": "gaussian", "gaussian_eps": 0.05}, max_graph_nodes=args.nodes)
+    b = build_PQ_batch(pos, gp, args.k, {"kernel": "gaussian", "gaussian_eps": 0.05}, max_graph_nodes=args.nodes,
+                       factored=args.factored)
+    Q = b["Q_factored"] if args.factored else b["Q"]
     graph_id = torch.arange(args.graphs, device=dev).repeat_interleave(args.nodes)
     # edge_index of the batch (no self loops), as batch.edge_index in the reference: (src, dst) = (col, row) of P's pattern
     pc = b["P"].csr(); rp = pc.rowptr.long()
@@ -41,21 +44,22 @@ def main():
     target = torch.from_numpy((clouds.max(1) - clouds.min(1)).max(1).astype(np.float32)).to(dev)
     torch.manual_seed(0)          # identical initial weights on every rank
     tr = DPTrainer(C=3, diffusion_kwargs=dict(scales_type="dyadic", J=4, include_lowpass=True), device=dev, amp_bf16=args.amp)
-    b["P"].csr().sell(); b["Q"].bsr3().sell()
+    b["P"].csr().sell()
+    (Q.signed.csr() if args.factored else Q.bsr3()).sell()
     losses = []
     for _ in range(args.warmup):
-        tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target, edge_index)
+        tr.step(pos, pos, b["P"], Q, graph_id, args.graphs, target, edge_index)
     if world > 1: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(tr.step(pos, pos, b["P"], b["Q"], graph_id, args.graphs, target, edge_index))
+        losses.append(tr.step(pos, pos, b["P"], Q, graph_id, args.graphs, target, edge_index))
     if world > 1: dist.barrier()
     torch.cuda.synchronize()
     dt = max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps({"workload": f"cfg4: DP training step, {args.graphs} graphs x {args.nodes} nodes per GPU, k={args.k}, J=4",
-                          "head_precision": "bf16 autocast" if args.amp else "fp32", "n_gpus": world, "graphs_per_s": args.graphs * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                          "head_precision": "bf16 autocast" if args.amp else "fp32", "vector_operator": "factored" if args.factored else "bsr3", "n_gpus": world, "graphs_per_s": args.graphs * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                           "params": tr.n_params(), "loss_first": float(losses[0]), "loss_last": float(losses[-1])}))
     if world > 1: dist.destroy_process_group()
 
