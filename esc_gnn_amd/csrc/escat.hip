@@ -126,23 +126,39 @@ k_csr_step(const int *__restrict__ rowptr, const int *__restrict__ col, const fl
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = 0.f;
         const int e1 = rowptr[row + 1];
-        for (int e = rowptr[row] + lg; e < e1; e += G) {
-            if constexpr (VP == 4) {             // |value| + three sign bits in the column word (bits 29..31)
-                const unsigned cw = (unsigned)col[e], vb = __float_as_uint(val[e]);
-                const float *x = xin + (int64_t)(cw & 0x1fffffffu) * ldx;
+        // four entries per lane and trip: their index/value loads go out together, then their x gathers together --
+        // two memory round trips per four entries instead of per entry (the step is latency-bound otherwise).  Slots past
+        // the row's end re-read the trip's first entry with a zero value.
+        constexpr int U = 4;
+        for (int e = rowptr[row] + lg; e < e1; e += G * U) {
+            unsigned cw[U]; float vv[U][VP == 3 ? 3 : 1];
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] += __uint_as_float(vb | ((cw << (2 - c)) & 0x80000000u)) * x[c];
-                continue;
+            for (int u = 0; u < U; ++u) {
+                const bool ok = e + u * G < e1;
+                const int eu = ok ? e + u * G : e;
+                cw[u] = (unsigned)col[eu];
+                if constexpr (VP == 3) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) vv[u][c] = ok ? val[(int64_t)eu * 3 + c] : 0.f;
+                } else vv[u][0] = ok ? val[eu] : 0.f;
             }
-            const float *x = xin + (int64_t)col[e] * ldx;
-            if constexpr (VP == 1) {
-                const float v = val[e];
+            float xr[U][C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] += v * x[c];
-            } else if constexpr (VP == 3) {
-                const float *v = val + (int64_t)e * VP;
+            for (int u = 0; u < U; ++u) {
+                const float *x = xin + (int64_t)(VP == 4 ? (cw[u] & 0x1fffffffu) : cw[u]) * ldx;
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] += v[c] * x[c];
+                for (int c = 0; c < C; ++c) xr[u][c] = x[c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v;
+                    if constexpr (VP == 4) v = __uint_as_float(__float_as_uint(vv[u][0]) | ((cw[u] << (2 - c)) & 0x80000000u));
+                    else if constexpr (VP == 3) v = vv[u][c % 3];
+                    else v = vv[u][0];
+                    acc[c] += v * xr[u][c];
+                }
             }
         }
 #pragma unroll
