@@ -14,12 +14,14 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--sort-axis", type=int, default=None)
     ap.add_argument("--check", action="store_true", help="telescoping-sum property check on the result")
+    ap.add_argument("--gen-workers", type=int, default=-1, help="processes for the kNN of the cloud (-1: up to 16; 1 under rocprofv3)")
     ap.add_argument("--factored", action="store_true",
                     help="also run the vector operator in factored form (frames + signed scalar operator, 8 B per nonzero)")
     args = ap.parse_args()
     from esc_gnn_amd import synthetic
     t0 = time.time()
-    b = synthetic.single_cloud(args.n, args.k, workers=min(16, os.cpu_count()), sort_axis=args.sort_axis)
+    b = synthetic.single_cloud(args.n, args.k, workers=min(16, os.cpu_count()) if args.gen_workers < 0 else args.gen_workers,
+                               sort_axis=args.sort_axis)
     gen_s = time.time() - t0
     import torch
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain
