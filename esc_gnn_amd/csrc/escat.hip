@@ -1022,8 +1022,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         STAMP(li, 1);
         // ... and store the previous part's result underneath the stream
         if (prev_rows >= 0) {
-            if constexpr (Op::FRAMES && !ORD) if (sd.frames) {     // back to global coordinates (uniform branch)
-                if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, F, 3 * F, F);
+            if constexpr (Op::FRAMES) if (sd.frames) {     // back to global coordinates (uniform branch)
+                if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs);   // ORD: [x | bank]
                 else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
                 __syncthreads();
             }
@@ -1042,7 +1042,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         if (prev_rows < 0 || (BWD && !early)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                          // every wave's copy has landed; the epilogue's LDS reads are done
         STAMP(li, 3);
-        if constexpr (Op::FRAMES && !ORD) if (sd.frames) {         // the staged input, into the local frames
+        if constexpr (Op::FRAMES) if (sd.frames) {         // the staged input, into the local frames
             if (!BWD) rotate_rows<true, NT>(inb, sd.frames + (int64_t)gs * 9, rows, 1, 3, 1);
             else rotate_rows<true, NT>(slab, sd.frames + (int64_t)gs * 9, rows, F, 3 * F, F);
             __syncthreads();
@@ -1107,8 +1107,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         li = liN; part = partN; row0 = row0N; rt = rtN; te0 = te0N; sw = swN;
         if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
     }
-    if constexpr (Op::FRAMES && !ORD) if (sd.frames) {
-        if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, F, 3 * F, F);
+    if constexpr (Op::FRAMES) if (sd.frames) {
+        if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs);   // ORD: [x | bank]
         else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
         __syncthreads();
     }
@@ -1473,7 +1473,6 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
     sd->planes = sell->val_planes >= 3 ? sell->val_planes : 1;
     sd->frames = sell->frames;
     if (sd->frames && sd->planes < 3) return fail(ESCAT_EINVAL, "escat_sell.frames goes with val_planes = 3");
-    if (sd->frames && sd->orders) return fail(ESCAT_EINVAL, "escat_sell.frames and .orders exclude each other");
     return ESCAT_OK;
 }
 

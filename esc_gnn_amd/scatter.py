@@ -65,9 +65,15 @@ def _scatter_rows(x, P_or_Q, dkw, second_order):
             plan = plan_chain(scales_type=dkw.get('scales_type', 'dyadic'), diffusion_scales=dkw.get('diffusion_scales', None),
                               J=dkw.get('J', 5), include_lowpass=dkw.get('include_lowpass', True))
             op = as_operator(P_or_Q)
+            if isinstance(op, FactoredVectorOperator):
+                # the kernel rotates [x | bank] back to global coordinates in LDS before it forms the products
+                if x.shape[1] == 1 and op.n == x.shape[0] and not plan.per_channel and op.fits_register_path(plan.F):
+                    W = _chain_launch(op.signed, plan.events, plan.T, plan.F, x.view(-1, 3).contiguous(), 3, False,
+                                      orders=2 if second_order else 1, frames=op.frames)
+                    return W.view(x.shape[0], 1, -1)
+                raise NoFusedOrders()
             base = op.base if isinstance(op, OperatorBatch) else op
-            # (a factored vector operator rotates the bank back to global coordinates before the products are formed)
-            ok = not isinstance(op, FactoredVectorOperator) and op.n == x.shape[0] and base.row_perm is None and (not plan.per_channel or plan.n_channels == x.shape[1])
+            ok = op.n == x.shape[0] and base.row_perm is None and (not plan.per_channel or plan.n_channels == x.shape[1])
             if ok:
                 # one launch: [x | bank | pair products] written by the chain's own epilogue (escat_sell.orders)
                 return _chain_launch(op, plan.events, plan.T, plan.F, x.contiguous(), x.shape[1], False,
