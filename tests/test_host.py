@@ -268,3 +268,29 @@ def test_scattering_cache_keys():
     assert c.hits == 2 and c.misses == 8
     c.clear()
     assert c.lookup("scalar", x, op, dict(scales_type="custom", diffusion_scales=ds), False) is None
+
+
+def test_signed_pack_of_per_channel_values(monkeypatch):
+    """|value| + three sign bits in the column word (escat_sell.val_planes = 4): host-side packing logic."""
+    from esc_gnn_amd.operators import _Csr
+    rowptr = torch.tensor([0, 2, 3, 5], dtype=torch.int32)
+    col = torch.tensor([0, 2, 1, 0, 2], dtype=torch.int32)
+    p = torch.tensor([0.5, 0.25, 1.0, 0.125, 0.75])
+    sgn = torch.tensor([[1, 1, 1], [-1, 1, -1], [1, -1, 1], [-1, -1, -1], [1, 1, -1]], dtype=torch.float32)
+    parts = (torch.tensor([0, 3], dtype=torch.int32), 1, 3)
+    form = _Csr(rowptr, col, (p[:, None] * sgn).contiguous(), 3, parts)
+    colp, mag, bits = form.signed_pack()
+    assert torch.equal(colp & 0x1fffffff, col) and torch.equal(mag, p)
+    want_bits = ((sgn[:, 0] < 0).int() | ((sgn[:, 1] < 0).int() << 1) | ((sgn[:, 2] < 0).int() << 2))
+    assert torch.equal(bits, want_bits) and torch.equal((colp >> 29) & 7, want_bits)
+    # decoding the way the kernels do: value_c = |v| with the sign bit of channel c
+    dec = torch.stack([torch.where(((colp >> (29 + c)) & 1) == 1, -mag, mag) for c in range(3)], dim=1)
+    assert torch.equal(dec, form.val)
+    # unrelated per-channel values have no such form; nor has anything with ESCAT_FACTORED_FORMAT=planes
+    assert _Csr(rowptr, col, torch.rand(5, 3) + 0.1, 3, parts).signed_pack() is None
+    monkeypatch.setenv("ESCAT_FACTORED_FORMAT", "planes")
+    assert _Csr(rowptr, col, (p[:, None] * sgn).contiguous(), 3, parts).signed_pack() is None
+    # a zero value carries no sign
+    z = _Csr(rowptr, col, torch.zeros(5, 3) * -1.0, 3, parts)
+    monkeypatch.delenv("ESCAT_FACTORED_FORMAT")
+    assert int(z.signed_pack()[2].sum()) == 0
