@@ -128,10 +128,17 @@ def main():
     import torch.distributed as dist
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain, load_library
     load_library()                      # raises if libescat.so is missing: no fallback
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ESCAT_BENCH_REHEARSAL=1: exercise the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
+    # gloo instead of RCCL).  For checking the script, not for numbers.
+    rehearsal = os.environ.get("ESCAT_BENCH_REHEARSAL", "") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     t = lambda a: torch.from_numpy(a).to(dev)
     rowptr, col = t(b["rowptr"]), t(b["col"])
@@ -194,7 +201,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     from esc_gnn_amd.dist_utils import max_over_ranks
-    dt = max_over_ranks(dt, dev)
+    dt = max_over_ranks(dt, None if rehearsal else dev)
 
     if rank == 0:
         per = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i, nm in enumerate(names)}
