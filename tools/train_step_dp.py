@@ -24,10 +24,12 @@ def main():
     from esc_gnn_amd.process_pyg_data import build_PQ_batch
     from esc_gnn_amd.train_dp import DPTrainer
     rank, local_rank, world = env_rank_world()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = os.environ.get("ESCAT_BENCH_REHEARSAL", "") == "1"    # ranks share devices, gloo: script check only
+    di = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo") if rehearsal else dist.init_process_group("nccl", device_id=dev)
     clouds = synthetic.ellipsoid_clouds(args.graphs, args.nodes, seed=457892 + rank)
     pos = torch.from_numpy(clouds.reshape(-1, 3)).to(dev)
     gp = torch.arange(args.graphs + 1, dtype=torch.int32, device=dev) * args.nodes
@@ -56,7 +58,7 @@ def main():
         losses.append(tr.step(pos, pos, b["P"], Q, graph_id, args.graphs, target, edge_index))
     if world > 1: dist.barrier()
     torch.cuda.synchronize()
-    dt = max_over_ranks(time.perf_counter() - t0, dev)
+    dt = max_over_ranks(time.perf_counter() - t0, None if rehearsal else dev)
     if rank == 0:
         print(json.dumps({"workload": f"cfg4: DP training step, {args.graphs} graphs x {args.nodes} nodes per GPU, k={args.k}, J=4",
                           "head_precision": "bf16 autocast" if args.amp else "fp32", "vector_operator": "factored" if args.factored else "bsr3", "n_gpus": world, "graphs_per_s": args.graphs * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
