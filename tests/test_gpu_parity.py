@@ -668,3 +668,32 @@ def test_properties_at_full_cfg2_size():
     assert S.shape == (N, 3, 1 + F + F * (F - 1) // 2)
     assert torch.equal(S[..., 0], x) and torch.equal(S[..., 1:1 + F], Wx)
     assert (S[..., 1 + F:] - Wx[..., iu[0]] * Wx[..., iu[1]]).abs().max() <= 1e-6 * S.abs().max()
+
+
+def test_large_cloud_properties():
+    """BASELINE cfg3 in kind (one connected cloud, k = 16, J = 6, vector track; 200 000 points so that the host kNN stays
+    within seconds): the multi-launch path with the breadth-first relabelling, BSR-3 and factored form.  Properties:
+    telescoping sum = x, adjointness of backward, agreement of the two operator forms."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, FactoredVectorOperator, synthetic
+    dev = _dev()
+    c = synthetic.single_cloud(200_000, 16, workers=1)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    none = (torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
+    opQ = ScatterOperator.from_bsr3(t(c["rowptr"]), t(c["col"]), t(c["blk"]), c["N"], parts=none)
+    fop = FactoredVectorOperator.from_frames(t(c["rowptr"]), t(c["col"]), t(c["pval"]), t(c["frames"]), parts=none)
+    assert opQ.row_perm is not None and fop.signed.row_perm is not None          # relabelled for locality
+    xv = t(c["pos"]).reshape(-1, 1)
+    Ws = {}
+    for name, op in (("bsr3", opQ), ("factored", fop)):
+        x = xv.clone().requires_grad_(True)
+        W = get_Batch_Wjxs(x, op, J=6)
+        assert W.shape == (3 * c["N"], 1, 8)
+        assert (W.detach().sum(-1).reshape(-1) - xv.reshape(-1)).abs().max() < 5e-6 * float(xv.abs().max())
+        G = torch.randn(W.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        (W * G).sum().backward()
+        lhs = (W.detach().double() * G.double()).sum()
+        rhs = (x.detach().double() * x.grad.double()).sum()
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+        Ws[name] = W.detach()
+    d = (Ws["factored"] - Ws["bsr3"]).abs().amax(dim=(0, 1)) / Ws["bsr3"].abs().amax(dim=(0, 1))
+    assert float(d.max()) <= 1e-5
