@@ -1313,6 +1313,10 @@ static int grid_for(int64_t work_items, int per_block)
 
 static int pick_G(int64_t n, int64_t nnz)
 {
+    if (const char *e = getenv("ESCAT_CSR_G")) {        // tuning aid: lanes per row of the lane-group CSR kernels
+        const int g = atoi(e);
+        if (g == 4 || g == 8 || g == 16) return g;
+    }
     const double mean = n > 0 ? (double)nnz / (double)n : 0.0;
     return mean <= 6.0 ? 4 : (mean <= 24.0 ? 8 : 16);
 }
