@@ -9,6 +9,7 @@ There is no CPU path: tensors must live on the GPU and the HIP library must be
 built, otherwise this raises.
 """
 import ctypes
+import functools
 import os
 from typing import Optional
 import torch
@@ -21,7 +22,9 @@ LDS_BUDGET = 160 * 1024
 MAX_C = 8
 
 
+@functools.lru_cache(maxsize=512)
 def _events_array(events):
+    """ctypes copy of a plan's event tuple (cached: plans are few and immutable; filling the array costs ~1 us an event)"""
     arr = (_lib.EscatEvent * max(len(events), 1))()
     for k, (step, slot, sign, chan) in enumerate(events):
         arr[k].step, arr[k].slot, arr[k].sign, arr[k].chan = step, slot, sign, chan
