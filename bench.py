@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy)
+LDS_PEAK_GBS = 150000.0   # MI355X_MICROARCH.md, LDS: ~150 TB/s aggregate for ds_read_b64/b128 with every CU streaming
 
 
 def alg_bytes_scalar(N, nnz, C, T, F):
@@ -53,14 +54,27 @@ def compulsory_bytes_vector(N, nnz, F):
     return 38 * nnz + 4 * (N + 1) + 12 * N + 12 * N * F
 
 
+def lib_sha256():
+    """hash of the built product library: the measured-traffic summary is only valid for the kernels it was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(os.path.join(ROOT, "esc_gnn_amd", "libescat.so"), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def measured_traffic(args, kernel_key, kernel_end=""):
-    """HBM bytes per launch from the committed PMC summary (profiles/hbm_traffic.json), if it is for this workload."""
+    """HBM bytes per launch from the committed PMC summary (profiles/hbm_traffic.json) -- only if it was taken on this
+    workload AND with this very libescat.so (sha256 stamp written by tools/pmc_to_traffic.py); otherwise None."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     except Exception:
         return None
     c = t.get("config", {})
     if (c.get("graphs"), c.get("nodes"), c.get("k"), c.get("J")) != (args.graphs, args.nodes, args.k, args.J):
+        return None
+    if t.get("libescat_sha256") != lib_sha256():
         return None
     for name, v in t.get("kernels", {}).items():
         if name.startswith(kernel_key) and name.endswith(kernel_end):
@@ -112,11 +126,31 @@ def main():
                     help="processes for input generation (-1: up to 16; use 1 under rocprofv3: no fork after GPU init)")
     args = ap.parse_args()
 
+    rehearsal = os.environ.get("ESCAT_BENCH_REHEARSAL", "") == "1"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the N ranks ourselves, as child processes, BEFORE anything here touches the GPU
+        # (torch.cuda.device_count() does not initialise it), and leave with the launcher's exit code
+        import subprocess
+        import socket
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus and not rehearsal:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+            raise SystemExit(2)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        raise SystemExit(2)
 
     # ---- inputs (host, before the GPU is touched: the generator forks workers)
     from esc_gnn_amd import synthetic
@@ -130,7 +164,9 @@ def main():
     load_library()                      # raises if libescat.so is missing: no fallback
     # ESCAT_BENCH_REHEARSAL=1: exercise the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
     # gloo instead of RCCL).  For checking the script, not for numbers.
-    rehearsal = os.environ.get("ESCAT_BENCH_REHEARSAL", "") == "1"
+    if torch.cuda.device_count() < (1 if rehearsal else (local_rank + 1 if world > 1 else 1)):
+        print(f"bench.py: rank {rank} needs cuda:{local_rank}, {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        raise SystemExit(2)
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -206,14 +242,31 @@ def main():
     dt = time.perf_counter() - t0
     from esc_gnn_amd.dist_utils import max_over_ranks
     dt = max_over_ranks(dt, None if rehearsal else dev)
+    # what the collective backend itself saw: every rank adds 1 (RCCL all-reduce on the GPU; gloo in rehearsal)
+    ranks_seen, backend = 1, "none"
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(one)
+        ranks_seen, backend = int(one.item()), dist.get_backend()
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            print(f"bench.py: {ranks_seen} ranks answered the all-reduce, --gpus {args.gpus}", file=sys.stderr)
+            raise SystemExit(3)
 
     if rank == 0:
         per = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i, nm in enumerate(names)}
         bytes_q = alg_bytes_vector(N, nnz, T, F)
         bytes_p = alg_bytes_scalar(N, nnz, C, T, F)
-        achieved = bytes_q / (per["Q_fwd"] * 1e-3) / 1e9
+        alg_gbs = bytes_q / (per["Q_fwd"] * 1e-3) / 1e9
         comp_q = compulsory_bytes_vector(N, nnz, F)
         traffic = measured_traffic(args, "k_chain_sell<OpBsr3", ", false, false>")
+        hbm_bytes = traffic if traffic is not None else comp_q
+        achieved = hbm_bytes / (per["Q_fwd"] * 1e-3) / 1e9
+        # LDS side of the same kernel: every step gathers 16 B per stored block and stores each node's new vector twice
+        lds_bytes = T * (16 * nnz + 2 * 16 * N)
+        lds_gbs = lds_bytes / (per["Q_fwd"] * 1e-3) / 1e9
+        step_bytes = sum((measured_traffic(args, k, e) or 0) for k, e in
+                         (("k_chain_sell<OpBsr3", ", false, false>"), ("k_chain_sell<OpBsr3", ", true, false>"),
+                          ("k_chain_sell<OpCsr<3", ", false, false>"), ("k_chain_sell<OpCsr<3", ", true, false>")))
         out = {
             "metric": "graphs/sec for P+Q scattering fwd+bwd (J=4)",
             "value": args.graphs * world * args.steps / dt,
@@ -226,24 +279,31 @@ def main():
                                    f"P (CSR, C=3) + Q (BSR-3) dyadic J={args.J} + lowpass, fwd+bwd",
                        "graphs_per_gpu": args.graphs, "nodes_per_graph": args.nodes, "k": args.k, "J": args.J,
                        "N": N, "nnz_P": nnz, "T": T, "F": F, "parallelism": f"dp{world} (graph shards, no data-path collective)"},
+            "collective_backend": backend, "ranks_seen_by_allreduce": ranks_seen,
             "roofline": {"bound": "hbm", "kernel": "k_chain_sell<OpBsr3<..>, 512, false, false> (Q chain forward)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_q, "ms_per_launch": per["Q_fwd"],
+                         "bytes_basis": "measured (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/hbm_traffic.json, same libescat.so)"
+                                        if traffic is not None else
+                                        "compulsory bytes (operator read once + x in + bank out): no PMC summary for this build",
+                         "ms_per_launch": per["Q_fwd"],
                          "compulsory_bytes_per_launch": comp_q,
-                         "hbm_achieved": (traffic or comp_q) / (per["Q_fwd"] * 1e-3) / 1e9,
-                         "hbm_frac": (traffic or comp_q) / (per["Q_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "hbm_frac_of_measured_copy": (traffic or comp_q) / (per["Q_fwd"] * 1e-3) / 1e9 / copy_gbs,
-                         "regime": "achieved/frac use SURVEY.md 8d's algorithmic bytes (operator streamed once per step, "
-                                   "T=16). This kernel keeps each graph's operator in registers for all T steps, so real HBM "
-                                   "traffic is the compulsory ~1/14 of that (traffic, from rocprofv3 FETCH_SIZE/WRITE_SIZE); "
-                                   "hbm_achieved/hbm_frac = measured traffic / time vs the 8 TB/s peak. frac > 1 is the "
-                                   "re-read elimination, not a bandwidth claim."},
+                         "frac_of_measured_copy": achieved / copy_gbs,
+                         "algorithmic_bytes_per_launch": bytes_q, "algorithmic_GBs": alg_gbs,
+                         "whole_step_hbm_frac": (step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if step_bytes and traffic else None,
+                         "lds": {"bytes": lds_bytes, "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                 "frac": lds_gbs / LDS_PEAK_GBS,
+                                 "note": "T*(16 B gathered per block + two 16-B vector stores per node) vs ~150 TB/s aggregate "
+                                         "ds_read_b128 rate (MI355X_MICROARCH.md, LDS)"},
+                         "regime": "the kernel keeps each graph's operator in registers for all T steps: HBM carries the "
+                                   "operator once per chain (achieved/frac = those bytes / time vs the 8 TB/s peak); "
+                                   "algorithmic_GBs is SURVEY.md 8d's figure (operator re-streamed every step) for reference "
+                                   "only and is not a bandwidth."},
             "hbm_copy_measured_GBs": copy_gbs,
             "canonicalise_ms_once_per_batch": canon_ms,
             "canonicalise_ms_first_call_in_process": canon_first_ms,
             "kernels_ms": per,
-            "kernels_alg_GBs": {"P_fwd": bytes_p / (per["P_fwd"] * 1e-3) / 1e9, "Q_fwd": achieved,
+            "kernels_alg_GBs": {"P_fwd": bytes_p / (per["P_fwd"] * 1e-3) / 1e9, "Q_fwd": alg_gbs,
                                 "P_bwd": bytes_p / (per["P_bwd"] * 1e-3) / 1e9,
                                 "Q_bwd": bytes_q / (per["Q_bwd"] * 1e-3) / 1e9},
         }

@@ -1,0 +1,643 @@
+// escat_sell_kernel.h -- the register-resident chain kernel (k_chain_sell) and its operator flavours; included by the
+// escat_sell_*.hip translation units, which instantiate it per operator family (parallel builds).
+#ifndef ESCAT_SELL_KERNEL_H
+#define ESCAT_SELL_KERNEL_H
+#include "escat_dev.h"
+
+// debug build only (-DESCAT_STAMPS, see tools/stamps.py): wall-clock stamps of the phases of every part
+#ifdef ESCAT_STAMPS
+static __device__ unsigned long long *g_stamps = nullptr;
+#define STAMP(part, i) do { if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)(part) * 16 + (i)] = wall_clock64(); } while (0)
+#define STAMPW(part, i, tid) do { if (g_stamps && threadIdx.x == (tid)) g_stamps[(size_t)(part) * 16 + (i)] = wall_clock64(); } while (0)
+#define ESCAT_STAMP_SETTER(name) extern "C" int name(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#else
+#define STAMP(part, i)
+#define STAMPW(part, i, tid)
+#endif
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int CP> struct XVec;
+template <> struct XVec<1> { float v[1];
+    __device__ __forceinline__ void load(const float *p) { v[0] = p[0]; }
+    __device__ __forceinline__ void store(float *p) const { p[0] = v[0]; } };
+template <> struct XVec<2> { float v[2];
+    __device__ __forceinline__ void load(const float *p) { const float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]); } };
+template <> struct XVec<4> { float v[4];
+    __device__ __forceinline__ void load(const float *p) { const float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); } };
+template <> struct XVec<8> { float v[8];
+    __device__ __forceinline__ void load(const float *p) {
+        const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; }
+    __device__ __forceinline__ void store(float *p) const {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]); } };
+
+// ---- LDS gathers with an explicit software pipeline.  The loads are inline asm, so the compiler neither narrows them
+// (a float4 gather whose pad lane is dead becomes ds_read_b96: 8 LDS cycles instead of 4) nor places its own waits: with
+// compiler-visible loads the s_waitcnt it derived alternated lgkmcnt(1) / lgkmcnt(0) -- at most two gathers in flight,
+// which leaves the step loop bound by LDS latency (2 waves per SIMD).  lds_wait<N>() returns once at most N later LDS
+// operations of the wave are outstanding; it is tied to the destination registers so that no use moves above it.
+template <int CP> struct LdsRow;
+template <> struct LdsRow<1> { typedef float T; };
+template <> struct LdsRow<2> { typedef vf2 T; };
+template <> struct LdsRow<4> { typedef vf4 T; };
+__device__ __forceinline__ void lds_gather(float &d, unsigned a) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(a)); }
+__device__ __forceinline__ void lds_gather(vf2 &d, unsigned a) { asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"(a)); }
+__device__ __forceinline__ void lds_gather(vf4 &d, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); }
+template <int N, class T> __device__ __forceinline__ void lds_wait(T &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+__device__ __forceinline__ unsigned lds_addr(const float *p) { return (unsigned)(uintptr_t)(lds_void_t *)p; }
+
+// ---- the operator of one row, in registers.  Two flavours with one interface:
+//   load(sd, doff, poff, w, lane)  issue the (coalesced) loads of this lane's slots
+//   gather(xa, w, acc)          acc += sum over slots of value * x[LDS row]   (one step)
+//   tail(...)                   entries beyond dmax, streamed
+template <int DMAX> struct OpBsr3 {
+    static constexpr bool FRAMES = false;
+    static constexpr int C = 3, CP = 4, MINW = 1;
+    static constexpr int RING = 4;                // LDS gathers in flight per lane (4 VGPRs each)
+    // a block's 9 floats as the three pieces they are loaded in, ordered for packed fp32 math:
+    //   b0 = (b00, b10, b01, b11)   b1 = (b02, b12, b20, b21)   b2 = b22       (bij = row i, column j of the block)
+    // so that (y0, y1) += (b0j, b1j) * xj is one v_pk_fma_f32 per column j (xj broadcast by op_sel) and
+    // (b20, b21) * (x0, x1) another: 5 VALU instructions per block instead of 9.
+    vf4 b0[DMAX], b1[DMAX];
+    float b2[DMAX];
+    unsigned lc[(DMAX + 1) / 2];
+    // Every slot register is written by exactly one UNCONDITIONAL load per part: a slot past the slice's width re-reads
+    // the last real slot (same address for the whole wave: served by the cache) and is never consumed, gather() stops at
+    // the width.  Written with a branch per slot ("load if d < w, else keep / zero") the compiler merges loaded and
+    // kept values through register copies that need the data -- a vmcnt(0) after every slot, i.e. twenty serial HBM
+    // round trips per part instead of one burst (measured with tools/stamps.py: 16 us vs the ~9 us the bytes take).
+    __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)
+    {
+        const float *vb = sd.val + (int64_t)doff * 576;
+        const int wl = w > 0 ? w - 1 : 0;         // (an empty slice reads the pack's padding slot)
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            const int dd = d < wl ? d : wl;       // wave-uniform
+            b0[d] = *reinterpret_cast<const vf4 *>(vb + dd * 576 + lane * 4);
+            b1[d] = *reinterpret_cast<const vf4 *>(vb + dd * 576 + 256 + lane * 4);
+            b2[d] = vb[dd * 576 + 512 + lane];
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < (DMAX + 1) / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
+    }
+    // One step of this lane's row.  gather() dispatches (wave-uniform) on the slice's width, rounded up to 2, to a
+    // straight-line body for exactly that many slots: the LDS gathers run GATHER_AHEAD slots ahead of the FMAs in a ring
+    // of registers, so a wave always has gathers in flight (two waves per SIMD cannot hide LDS latency by themselves),
+    // and without branches in the body the compiler can count them (s_waitcnt lgkmcnt(N), not 0).  The odd slot of a
+    // rounded-up width re-reads a real block against the all-zero row.
+    __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    template <int W>
+    __device__ __forceinline__ void gather_w(const float *xa, vf2 &a01, vf2 &t2, float &a2) const
+    {
+        constexpr int D = RING;
+        vf4 xv[D];
+        const unsigned base = lds_addr(xa);
+#pragma unroll
+        for (int d = 0; d < D && d < W; ++d) lds_gather(xv[d], base + row_of(d) * 16u);   // a row is 4 floats
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            // gather d has landed once at most min(D-1, W-1-d) younger ones are outstanding (LDS returns in order)
+            if (W - 1 - d >= D - 1) lds_wait<D - 1>(xv[d % D]);
+            else if (W - 1 - d == 6) lds_wait<6>(xv[d % D]);
+            else if (W - 1 - d == 5) lds_wait<5>(xv[d % D]);
+            else if (W - 1 - d == 4) lds_wait<4>(xv[d % D]);
+            else if (W - 1 - d == 3) lds_wait<3>(xv[d % D]);
+            else if (W - 1 - d == 2) lds_wait<2>(xv[d % D]);
+            else if (W - 1 - d == 1) lds_wait<1>(xv[d % D]);
+            else lds_wait<0>(xv[d % D]);
+            const vf4 x = xv[d % D];
+            a01 = __builtin_elementwise_fma(b0[d].xy, x.xx, a01);
+            a01 = __builtin_elementwise_fma(b0[d].zw, x.yy, a01);
+            a01 = __builtin_elementwise_fma(b1[d].xy, x.zz, a01);
+            t2 = __builtin_elementwise_fma(b1[d].zw, x.xy, t2);
+            a2 = fmaf(b2[d], x.z, a2);
+            if (d + D < W) {
+                // the slot just consumed takes the next gather; the empty asm statements pin this slot's FMAs before it
+                // (volatile asm keeps its order: without them the scheduler sinks the FMAs and renames the ring away)
+                asm volatile("" :: "v"(a01), "v"(t2), "v"(a2));
+                lds_gather(xv[d % D], base + row_of(d + D) * 16u);
+            }
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, vf2 &a01, vf2 &t2, float &a2) const
+    {
+        if constexpr (W <= DMAX) {
+            if (w2 == W / 2) gather_w<W>(xa, a01, t2, a2);
+            else dispatch<W + 2>(w2, xa, a01, t2, a2);
+        }
+    }
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&a)[3]) const
+    {
+        vf2 a01 = {0.f, 0.f}, t2 = {0.f, 0.f};    // (y0, y1) and the two-column partial sums of y2
+        float a2 = 0.f;
+        dispatch<2>((w + 1) >> 1, xa, a01, t2, a2);
+        a[0] += a01.x; a[1] += a01.y; a[2] += a2 + (t2.x + t2.y);
+    }
+    static __device__ __forceinline__ void tail(const float *__restrict__ blk, const int *__restrict__ col, int e0, int n,
+                                                int gs, const float *xa, float (&a)[3])
+    {
+        for (int e = e0; e < e0 + n; ++e) {       // rows longer than the pack: from L2, every step
+            const float *bb = blk + (int64_t)e * 9;
+            const float *x = xa + (col[e] - gs) * 4;
+            const float x0 = x[0], x1 = x[1], x2 = x[2];
+            a[0] = fmaf(bb[0], x0, a[0]); a[0] = fmaf(bb[1], x1, a[0]); a[0] = fmaf(bb[2], x2, a[0]);
+            a[1] = fmaf(bb[3], x0, a[1]); a[1] = fmaf(bb[4], x1, a[1]); a[1] = fmaf(bb[5], x2, a[1]);
+            a[2] = fmaf(bb[6], x0, a[2]); a[2] = fmaf(bb[7], x1, a[2]); a[2] = fmaf(bb[8], x2, a[2]);
+        }
+    }
+};
+
+template <int CC, int DMAX> struct OpCsr {
+    static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
+    static constexpr bool FRAMES = false;
+    static constexpr int C = CC, CP = CC == 1 ? 1 : (CC == 2 ? 2 : (CC <= 4 ? 4 : 8));
+    static constexpr int MINW = 4;                // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
+    float v[DMAX];
+    unsigned lc[DMAX / 2];
+    __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)   // see OpBsr3::load
+    {
+        const int wl = w > 0 ? w - 1 : 0;
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = sd.val[(int64_t)(doff + (d < wl ? d : wl)) * 64 + lane];
+#pragma unroll
+        for (int j2 = 0; j2 < DMAX / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];     // LDS rows, two per register
+    }
+    __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    static constexpr int RING = CC <= 4 ? 6 : 3;  // gathers in flight per lane (CP / 4 or 2 x 4 VGPRs each)
+    template <int W>
+    __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[CC]) const      // see OpBsr3::gather_w
+    {
+        constexpr int D = RING;
+        constexpr int PER = CP == 8 ? 2 : 1;     // LDS operations per gather
+        typedef typename LdsRow<(CP == 8 ? 4 : CP)>::T row_t;
+        row_t xv[D][PER];
+        const unsigned base = lds_addr(xa);
+#pragma unroll
+        for (int d = 0; d < D && d < W; ++d) {
+            lds_gather(xv[d][0], base + row_of(d) * (unsigned)(CP * 4));
+            if (PER == 2) lds_gather(xv[d][PER - 1], base + row_of(d) * (unsigned)(CP * 4) + 16u);
+        }
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            const int later = (W - 1 - d < D - 1 ? W - 1 - d : D - 1) * PER;     // younger LDS operations still allowed in flight
+            row_t &last = xv[d % D][PER - 1];
+            if (later >= 10) lds_wait<10>(last);
+            else if (later == 8) lds_wait<8>(last);
+            else if (later == 6) lds_wait<6>(last);
+            else if (later == 5) lds_wait<5>(last);
+            else if (later == 4) lds_wait<4>(last);
+            else if (later == 3) lds_wait<3>(last);
+            else if (later == 2) lds_wait<2>(last);
+            else if (later == 1) lds_wait<1>(last);
+            else lds_wait<0>(last);
+            if (PER == 2) asm volatile("" : "+v"(xv[d % D][0]));            // the first half landed before the second
+            float x[CP];
+            if constexpr (CP == 1) x[0] = xv[d % D][0];
+            else if constexpr (CP == 2) { x[0] = xv[d % D][0].x; x[1] = xv[d % D][0].y; }
+            else {
+#pragma unroll
+                for (int h = 0; h < PER; ++h) { x[4 * h] = xv[d % D][h].x; x[4 * h + 1] = xv[d % D][h].y; x[4 * h + 2] = xv[d % D][h].z; x[4 * h + 3] = xv[d % D][h].w; }
+            }
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = fmaf(v[d], x[c], acc[c]);
+            if (d + D < W) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) asm volatile("" :: "v"(acc[c]));      // see OpBsr3::gather_w
+                lds_gather(xv[d % D][0], base + row_of(d + D) * (unsigned)(CP * 4));
+                if (PER == 2) lds_gather(xv[d % D][PER - 1], base + row_of(d + D) * (unsigned)(CP * 4) + 16u);
+            }
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, float (&acc)[CC]) const
+    {
+        if constexpr (W <= DMAX) {
+            if (w2 == W / 2) gather_w<W>(xa, acc);
+            else dispatch<W + 2>(w2, xa, acc);
+        }
+    }
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[CC]) const { dispatch<2>((w + 1) >> 1, xa, acc); }
+    static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
+                                                int gs, const float *xa, float (&acc)[CC])
+    {
+        for (int e = e0; e < e0 + n; ++e) {
+            const float vv = val[e];
+            const float *x = xa + (col[e] - gs) * CP;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
+        }
+    }
+};
+
+
+// CSR with one value PER CHANNEL (three of them): y[i][c] = sum_j v[i,j][c] * x[j][c].  This is the vector operator in its
+// factored form: Q = D Pt D^T with D = blockdiag(O_i) and Pt_c[i,j] = p_ij * sign<O_i[:,c], O_j[:,c]> (what
+// process_pyg_data's column_dot alignment builds, process_pyg_data.py:306-313, :492), so Q^t = D Pt^t D^T and the chain
+// runs in the local frames on P's pattern with 12 B of values per nonzero instead of 36.  Same LDS layout and gathers
+// as OpCsr<3>; pack layout val[((doff_s + d) * 3 + c) * 64 + lane] (escat_sell.val_planes = 3).
+template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
+    static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
+    static constexpr int C = 3, CP = 4;
+    static constexpr int MINW = 4;                // <= 128 VGPRs (60 of them values): two 512-thread workgroups per CU
+    static constexpr int AHEAD = 2;               // gathers in flight (one fewer than OpCsr: the ring costs 4 VGPRs a stage)
+    static constexpr bool FRAMES = true;          // SellDev.frames != NULL: rotate in and out of the local frames in LDS
+    float v[DMAX][3];
+    unsigned lc[DMAX / 2];
+    __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)   // see OpBsr3::load
+    {
+        const int wl = w > 0 ? w - 1 : 0;
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+#pragma unroll
+        for (int j2 = 0; j2 < DMAX / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
+        if constexpr (!SIGNED) {
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const float *p = sd.val + (int64_t)(doff + (d < wl ? d : wl)) * 192 + lane;
+                v[d][0] = p[0]; v[d][1] = p[64]; v[d][2] = p[128];
+            }
+        } else {          // one plane of magnitudes from HBM; the signs ride in bits 11..13 of the slot's LDS-row field
+            float m[DMAX];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) m[d] = sd.val[(int64_t)(doff + (d < wl ? d : wl)) * 64 + lane];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                const unsigned f = field(d), mb = __float_as_uint(m[d]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[d][c] = __uint_as_float(mb | ((f << (20 - c)) & 0x80000000u));
+            }
+        }
+    }
+    __device__ __forceinline__ unsigned field(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
+    __device__ __forceinline__ unsigned row_of(int d) const { return SIGNED ? (field(d) & 0x7ffu) : field(d); }
+    template <int W>
+    __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[3]) const
+    {
+        XVec<4> xv[AHEAD + 1];
+#pragma unroll
+        for (int d = 0; d < AHEAD && d < W; ++d) xv[d].load(xa + row_of(d) * 4u);
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            if (d + AHEAD < W) xv[(d + AHEAD) % (AHEAD + 1)].load(xa + row_of(d + AHEAD) * 4u);
+            const XVec<4> &x = xv[d % (AHEAD + 1)];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = fmaf(v[d][c], x.v[c], acc[c]);
+            asm volatile("" :: "v"(x.v[3]));          // keep the gather a ds_read_b128
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, float (&acc)[3]) const
+    {
+        if constexpr (W <= DMAX) {
+            if (w2 == W / 2) gather_w<W>(xa, acc);
+            else dispatch<W + 2>(w2, xa, acc);
+        }
+    }
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[3]) const { dispatch<2>((w + 1) >> 1, xa, acc); }
+    static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
+                                                int gs, const float *xa, float (&acc)[3])
+    {
+        for (int e = e0; e < e0 + n; ++e) {
+            if constexpr (SIGNED) {          // global arrays in the packed form of k_csr_step<.., 4>
+                const unsigned cw = (unsigned)col[e], vb = __float_as_uint(val[e]);
+                const float *x = xa + ((int)(cw & 0x1fffffffu) - gs) * 4;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = fmaf(__uint_as_float(vb | ((cw << (2 - c)) & 0x80000000u)), x[c], acc[c]);
+            } else {
+                const float *x = xa + (col[e] - gs) * 4;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = fmaf(val[(int64_t)e * 3 + c], x[c], acc[c]);
+            }
+        }
+    }
+};
+
+
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// n floats global -> LDS without passing through registers (LDS-DMA, one dword per lane, 256 B per wave-instruction);
+// completion is counted in vmcnt like any load.
+template <int NT>
+__device__ __forceinline__ void dma_in(float *dst, const float *__restrict__ src, int n)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i0 = wave * 64; i0 < n; i0 += NT) {
+        const int i = i0 + lane;
+        if (i < n) __builtin_amdgcn_global_load_lds((glb_void_t *)(src + i), (lds_void_t *)(dst + i0), 4, 0, 0);
+    }
+}
+
+// builds the first vector of a part from its staged input (fwd: x in `inb`; bwd: the upstream-gradient slab), applies
+// the step-0 events (fwd) / forms the Horner start (bwd); returns the event cursor.  Ends with a barrier.
+// Fs / so: row stride of the slab and offset of slot 0 in it (Fs = F, so = 0; the fused-orders forward keeps x itself
+// in front of each row's bank: Fs = F + 1, so = 1).
+template <bool BWD, int NT>
+__device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab, const float *inb, int rows, int R, int C, int CP,
+                                              int F, int T, const EvTable &tab, int Fs = -1, int so = 0)
+{
+    if (Fs < 0) Fs = F;
+    const int tid = threadIdx.x;
+    const int nc = rows * C;
+    int p;
+    if (tid < CP) { xa[rows * CP + tid] = 0.f; xb[rows * CP + tid] = 0.f; }
+    if (!BWD) {
+        int p1 = 0; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
+        for (int i = tid; i < nc; i += NT) {
+            const int c = i % C, r = i / C; const float y = inb[i];
+            xa[r * CP + c] = y;
+            xa[(R + sell_copyB(r, R)) * CP + c] = y;
+            if (so) slab[i * Fs] = y;
+            for (int k = 0; k < p1; ++k)
+                if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * Fs + so, y, tab.e[k].slot, tab.e[k].sign);
+        }
+        p = p1;
+    } else {
+        int p0 = tab.n; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
+        for (int i = tid; i < nc; i += NT) {
+            const int c = i % C, r = i / C; float y = 0.f;
+            for (int k = p0; k < tab.n; ++k)
+                if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -slab[i * F + tab.e[k].slot] : slab[i * F + tab.e[k].slot];
+            xa[r * CP + c] = y;
+            xa[(R + sell_copyB(r, R)) * CP + c] = y;
+        }
+        p = p0;
+    }
+    __syncthreads();
+    return p;
+}
+
+// in-place rotation of a part's 3-vectors in LDS by the rows' local frames (global, L1/L2-resident: 36 B per row):
+// buf[r * rs + c * cs + f] <- sum_c' O_r[c][c'] (TR: O_r[c'][c]) buf[r * rs + c' * cs + f]; rows are independent.
+template <bool TR, int NT>
+__device__ __forceinline__ void rotate_rows(float *buf, const float *__restrict__ fr, int rows, int F, int rs, int cs)
+{
+    for (int r = threadIdx.x; r < rows; r += NT) {             // one thread per row: its frame is loaded once
+        const float *o = fr + r * 9;
+        const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7], o8 = o[8];
+        float *x = buf + r * rs;
+        for (int f = 0; f < F; ++f) {
+            const float x0 = x[f], x1 = x[cs + f], x2 = x[2 * cs + f];
+            if (TR) {
+                x[f]          = fmaf(o6, x2, fmaf(o3, x1, o0 * x0));
+                x[cs + f]     = fmaf(o7, x2, fmaf(o4, x1, o1 * x0));
+                x[2 * cs + f] = fmaf(o8, x2, fmaf(o5, x1, o2 * x0));
+            } else {
+                x[f]          = fmaf(o2, x2, fmaf(o1, x1, o0 * x0));
+                x[cs + f]     = fmaf(o5, x2, fmaf(o4, x1, o3 * x0));
+                x[2 * cs + f] = fmaf(o8, x2, fmaf(o7, x1, o6 * x0));
+            }
+        }
+    }
+}
+
+template <bool BWD, int NT>
+__device__ __forceinline__ void chain_epilogue(const float *xa, const float *slab, float *__restrict__ RES, int64_t first_row,
+                                               int rows, int C, int CP, int F)
+{
+    const int tid = threadIdx.x;
+    const int nc = rows * C;
+    if (!BWD) {
+        float *og = RES + first_row * C * F;
+        for (int i = tid; i < nc * F; i += NT) og[i] = slab[i];
+    } else {
+        float *dg = RES + first_row * C;
+        for (int i = tid; i < nc; i += NT) dg[i] = xa[(i / C) * CP + i % C];
+    }
+}
+
+// forward epilogue with the orders 0/1/2 of ESCGNNModular._scatter fused in (models/escgnn_modular.py:333-341): writes
+// (rows*C, Wtot) = [x | bank | bank_i * bank_j, i < j in triu order] straight from the LDS slab, so the bank itself
+// never goes to HBM and back.  The slab rows are [x | bank] in this mode (chain_prologue puts x there).
+// One thread per row-channel expands its slab row [x | bank] to Wtot values in an LDS tile (the two vector buffers are
+// dead by now), then the tile goes out as a contiguous run; no per-element index arithmetic.
+template <int NT>
+__device__ __forceinline__ void chain_epilogue_orders(const float *slab, float *tile, int tile_floats, float *__restrict__ RES,
+                                                      int64_t first_row, int rows, int C, int F, int second)
+{
+    const int wtot = 1 + F + (second ? F * (F - 1) / 2 : 0), Fs = F + 1;
+    const int nrc = rows * C, per = tile_floats / wtot;
+    float *og = RES + first_row * C * wtot;
+    for (int c0 = 0; c0 < nrc; c0 += per) {
+        const int n = nrc - c0 < per ? nrc - c0 : per;
+        for (int rc = threadIdx.x; rc < n; rc += NT) {
+            const float *srow = slab + (c0 + rc) * Fs;
+            float *o = tile + rc * wtot;
+            for (int f = 0; f <= F; ++f) o[f] = srow[f];
+            if (second) {
+                int q = 1 + F;
+                for (int i = 0; i < F; ++i) {
+                    const float a = srow[1 + i];
+                    for (int j = i + 1; j < F; ++j) o[q++] = a * srow[1 + j];
+                }
+            }
+        }
+        __syncthreads();
+        float *dst = og + (int64_t)c0 * wtot;
+        for (int i = threadIdx.x; i < n * wtot; i += NT) dst[i] = tile[i];
+        __syncthreads();
+    }
+}
+
+// ---- the register-resident chain kernel: persistent workgroups, software-pipelined over parts.
+// A workgroup walks parts blockIdx.x, + gridDim.x, ...  While part g steps, the metadata of part g' = g + gridDim.x
+// is fetched (one 12-B load per lane) and its input is copied into LDS by DMA; the moment g's last step is done --
+// its operator registers are dead -- the operator loads of g' are issued, and g's epilogue (slab -> HBM) and g''s
+// prologue (input -> first vector) run underneath them.  What stays exposed per part is the operator stream itself
+// (a CU pulls ~12-24 GB/s from HBM); the metadata hops, the input latency and the output stores are hidden.
+//   LDS: xa | xb (two copies each) | slab | inb   -- inb = staged x (fwd) or the second slab (bwd, `early`);
+//   bwd without room for two slabs (`early` = 0) copies the next input in after the last step instead.
+template <class Op, int NT, bool BWD, bool ORD>     // ORD: forward with the orders epilogue (a separate instantiation:
+__global__ void __launch_bounds__(NT, Op::MINW)      // compiled into the plain kernel, its code costs the step loop registers)
+k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev sd, const float *__restrict__ IN,
+             float *__restrict__ RES, int T, EvTable tab, int F, int n_parts, int max_rows, int early)
+{
+    constexpr int C = Op::C, CP = Op::CP;
+    extern __shared__ __align__(16) float smem[];
+    const int nv = 2 * sell_padR(max_rows) * CP;                 // two copies per vector, a multiple of 32 floats
+    const int so = ORD ? 1 : 0, Fs = F + so;                    // fused orders: slab rows are [x | bank]
+    const int slab_sz = (max_rows * C * Fs + 3) & ~3;
+    float *xa = smem, *xb = smem + nv, *slab = smem + 2 * nv;
+    float *inb = (BWD && !early) ? slab : slab + slab_sz;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int in_w = BWD ? C * F : C;                            // input floats per row
+
+    int li = blockIdx.x;                          // index into the launch's list of parts
+    if (li >= n_parts) return;
+    int part = sd.part_list ? sd.part_list[li] : li;            // part of the packed operator
+    int row0 = sd.part_row0 ? sd.part_row0[li] : -1;            // first row in IN / RES (-1: the operator's own)
+    Op op;
+    // first part: nothing to hide behind
+    int rt, te0, sw;
+    {
+        const int *lm = sd.lane_meta + ((int64_t)(part * sd.nsl + wave) * 64 + lane) * 3;
+        rt = lm[0]; te0 = lm[1]; sw = lm[2];
+        const int gs0 = __builtin_amdgcn_readlane(sw, 3), rows0 = __builtin_amdgcn_readlane(sw, 4);
+        if (row0 < 0) row0 = gs0;
+        dma_in<NT>(BWD ? slab : inb, IN + (int64_t)row0 * in_w, rows0 * in_w);
+    }
+    int prev_row0 = 0, prev_rows = -1, prev_gs = 0;   // part whose result is still in LDS (epilogue pending)
+    for (;;) {
+        // which part comes next (read now, needed after the prologue)
+        const int liN = li + gridDim.x;
+        const bool has_next = liN < n_parts;      // uniform
+        int partN = liN, row0N = -1;
+        if (has_next && sd.part_list) partN = sd.part_list[liN];
+        if (has_next && sd.part_row0) row0N = sd.part_row0[liN];
+
+        const int doff = __builtin_amdgcn_readlane(sw, 0), poff = __builtin_amdgcn_readlane(sw, 1);
+        const int w = __builtin_amdgcn_readlane(sw, 2);
+        const int gs = __builtin_amdgcn_readlane(sw, 3), rows = __builtin_amdgcn_readlane(sw, 4);
+        // the operator registers are dead here: refill them ...
+        STAMP(li, 0);
+        op.load(sd, doff, poff, w, lane);
+        STAMP(li, 1);
+        // ... and store the previous part's result underneath the stream
+        if (prev_rows >= 0) {
+            if constexpr (Op::FRAMES) if (sd.frames) {     // back to global coordinates (uniform branch)
+                if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs);   // ORD: [x | bank]
+                else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
+                __syncthreads();
+            }
+            if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
+            else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+        }
+        STAMP(li, 2);
+
+        const int R = sell_padR(rows);
+        const int r = (rt & 0x3ff) == 0x3ff ? -1 : (rt & 0x3ff);
+        const int tn = (int)((unsigned)rt >> 10);
+        const bool own = r >= 0;
+        const int rB = own ? R + sell_copyB(r, R) : 0;
+        // input staged?  (first part, or the late copy of the single-slab backward: wait for it -- and, loads being
+        // returned in order, for the operator issued after it; otherwise it landed many steps ago)
+        if (prev_rows < 0 || (BWD && !early)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                          // every wave's copy has landed; the epilogue's LDS reads are done
+        STAMP(li, 3);
+        if constexpr (Op::FRAMES) if (sd.frames) {         // the staged input, into the local frames
+            if (!BWD) rotate_rows<true, NT>(inb, sd.frames + (int64_t)gs * 9, rows, 1, 3, 1);
+            else rotate_rows<true, NT>(slab, sd.frames + (int64_t)gs * 9, rows, F, 3 * F, F);
+            __syncthreads();
+        }
+        int p = chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab, Fs, so);
+        STAMP(li, 4);
+
+        int rtN = 0, te0N = 0, swN = 0;
+        if (has_next) {                           // metadata of the next part: lands during the first step
+            const int *lm = sd.lane_meta + ((int64_t)(partN * sd.nsl + wave) * 64 + lane) * 3;
+            rtN = lm[0]; te0N = lm[1]; swN = lm[2];
+        }
+        bool staged = !(has_next && (!BWD || early));   // "nothing to stage early"
+        for (int t = 1; t <= T; ++t) {
+            int q0, q1;
+            step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
+            float acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#ifdef ESCAT_STAMPS
+            if (t == 5) { STAMPW(li, 8, 0); STAMPW(li, 12, NT - 64); }
+#endif
+            op.gather(xa, w, acc);
+#ifdef ESCAT_STAMPS
+            if (t == 5) { STAMPW(li, 9, 0); STAMPW(li, 13, NT - 64); }
+#endif
+            if (own) {
+                if (tn) Op::tail(val, col, te0, tn, gs, xa, acc);
+                XVec<CP> y;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
+                y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
+            }
+#ifdef ESCAT_STAMPS
+            if (t == 5) { STAMPW(li, 10, 0); STAMPW(li, 14, NT - 64); }
+#endif
+            __syncthreads();
+            float *tmp = xa; xa = xb; xb = tmp;
+#ifdef ESCAT_STAMPS
+            if (t == 1) STAMP(li, 5);
+            if (t == 5) { STAMPW(li, 11, 0); STAMPW(li, 15, NT - 64); }
+#endif
+            if (!staged) {                        // after the first step: start the DMA of the next part's input
+                const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
+                dma_in<NT>(inb, IN + (int64_t)(row0N < 0 ? gsN : row0N) * in_w, rowsN * in_w);
+                staged = true;
+            }
+        }
+        prev_row0 = row0; prev_rows = rows; prev_gs = gs;
+        STAMP(li, 6);
+        if (!has_next) break;
+        {
+            const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
+            if (row0N < 0) row0N = gsN;
+            // fwd / early bwd with T == 0 never reached the in-loop DMA; the single-slab bwd copies now (its slab is dead)
+            if (!staged || (BWD && !early)) dma_in<NT>(inb, IN + (int64_t)row0N * in_w, rowsN * in_w);
+            if (!BWD || early) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged long ago: costs nothing
+        }
+        STAMP(li, 7);
+        li = liN; part = partN; row0 = row0N; rt = rtN; te0 = te0N; sw = swN;
+        if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
+    }
+    if constexpr (Op::FRAMES) if (sd.frames) {
+        if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs);   // ORD: [x | bank]
+        else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
+        __syncthreads();
+    }
+    if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
+    else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+}
+
+template <class Op, int NT, bool BWD, bool ORD>
+static int launch_sell_k2(const int *ci, const float *v, int n_parts, int max_rows, const SellDev &sd, const float *IN,
+                          float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    int early = 0;
+    const int want = Op::MINW == 1 ? 1 : (NT == 512 ? 2 : 4);
+    const size_t lds = escat_sell_lds_bytes(Op::C, Op::CP, max_rows, F, BWD, want, &early, sd.orders);
+    if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "register-resident chain needs %zu B of LDS", lds);
+    if (ORD) {
+        // the orders epilogue expands whole output rows in a tile made of the two (dead) vector buffers: one row must fit,
+        // or its loop over row chunks never advances
+        const int wtot = 1 + F + (sd.orders == 2 ? F * (F - 1) / 2 : 0);
+        const int tile = 2 * 2 * sell_padR(max_rows) * Op::CP;
+        if (wtot > tile)
+            return fail(ESCAT_ERANGE, "escat_sell.orders: an output row of %d floats does not fit the %d-float LDS tile of parts "
+                                      "with <= %d rows (use the bank + escat_scatter_orders_f32)", wtot, tile, max_rows);
+    }
+    auto kern = k_chain_sell<Op, NT, BWD, ORD>;
+    int rc = set_lds(kern, lds); if (rc) return rc;
+    // resident workgroups per CU: cached per instantiation, LDS size and device (thread_local: no locking needed)
+    static thread_local size_t cached_lds = (size_t)-1; static thread_local int cached_per_cu = 0, cached_dev = -1;
+    int dev_now = 0;
+    (void)hipGetDevice(&dev_now);
+    if (cached_lds != lds || cached_dev != dev_now) {
+        int per = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, NT, lds) != hipSuccess || per < 1) per = 1;
+        cached_per_cu = per; cached_lds = lds; cached_dev = dev_now;
+    }
+    const int64_t resident = (int64_t)cached_per_cu * escat_cu_count();
+    const int grid = (int)(n_parts < resident ? n_parts : resident);           // persistent: one wave of workgroups
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ci, v, sd, IN, RES, T, tab, F, n_parts, max_rows, early);
+    return ESCAT_OK;
+}
+
+template <class Op, int NT, bool BWD>
+static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_rows, const SellDev &sd, const float *IN,
+                         float *RES, int T, const EvTable &tab, int F, hipStream_t st)
+{
+    if (sd.nsl * 64 != NT) return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d does not match parts of <= %d rows", sd.nsl, max_rows);
+    if (!BWD && sd.orders) return launch_sell_k2<Op, NT, false, true>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+    return launch_sell_k2<Op, NT, BWD, false>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+}
+
+#endif

@@ -38,7 +38,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
     """the slowest rank's time (what bench.py reports), identity when not distributed."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else None)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -67,5 +67,11 @@ class FlatGradBucket:
 
     def allreduce_mean(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.flat.is_cuda and dist.get_backend() == "gloo":
+                # rehearsal / tests (ranks sharing a GPU over gloo): stage through the host; the product path is RCCL
+                h = self.flat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                self.flat.copy_(h)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / dist.get_world_size())

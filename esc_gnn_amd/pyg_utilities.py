@@ -84,6 +84,13 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         sell = None
     if orders and sell is None:
         raise NoFusedOrders()
+    if orders:
+        # the fused epilogue expands whole output rows in an LDS tile made of the two vector buffers (csrc/escat.hip,
+        # chain_epilogue_orders): a row that does not fit (tiny parts, many bands) takes the two-kernel form
+        from .operators import sell_pad_rows
+        CPt = 4 if use_bsr else (1 if C == 1 else 2 if C == 2 else 4 if C <= 4 else 8)
+        if Wout > 2 * 2 * sell_pad_rows(form.max_part_rows) * CPt:
+            raise NoFusedOrders()
     if frames is not None and (use_bsr or form.val.dim() != 2):
         raise ValueError("escat: frames go with a CSR operator that has one value per channel")
     per_channel_vals = not use_bsr and form.val.dim() == 2
@@ -228,6 +235,19 @@ def bank(x: torch.Tensor, op, plan: ChainPlan) -> torch.Tensor:
     return _WaveletBank.apply(x, op, plan)
 
 
+ESCAT_EVENT_ABS = 256          # include/escat.h
+
+
+def abs_events(events):
+    """the event tuple with ESCAT_EVENT_ABS added to the sign of the last event of every (slot, channel): the chain then
+    keeps |value| in each slot, in the same pass (include/escat.h)."""
+    last = {}
+    for k, (_, slot, _, chan) in enumerate(events):
+        last[(slot, chan)] = k
+    closing = set(last.values())
+    return tuple((st, sl, sg + ESCAT_EVENT_ABS if k in closing else sg, ch) for k, (st, sl, sg, ch) in enumerate(events))
+
+
 def get_Batch_Wjxs(
     x: torch.Tensor,
     P_sparse,
@@ -237,6 +257,8 @@ def get_Batch_Wjxs(
     include_lowpass: bool = True,
     filter_stack_dim: int = -1,
     rescale_filtrations: bool = False,
+    *,
+    apply_abs: bool = False,
 ) -> torch.Tensor:
     """
     Diffusion-wavelet filter bank W_j x = (P^{a_{j-1}} - P^{a_j}) x (+ low-pass)
@@ -245,9 +267,16 @@ def get_Batch_Wjxs(
     sparse COO/CSR tensor (canonicalised once and cached on the tensor) or a
     prebuilt esc_gnn_amd.ScatterOperator.  Returns (N, C, F), fp32, on x.device,
     differentiable w.r.t. x.
+
+    apply_abs (keyword-only, NOT a reference argument, default off): return |W_j x| -- the modulus of LEGS-style callers
+    (models/comparisons/legs.py:299-302), applied by the chain kernel where it finalises each slot.  The drop-in path of
+    ESCGNNModular never sets it: the reference's _scatter keeps signed coefficients (models/escgnn_modular.py:326-341).
     """
     plan = plan_chain(scales_type=scales_type, diffusion_scales=diffusion_scales, J=J,
                       include_lowpass=include_lowpass)
+    if apply_abs and not (torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad):
+        plan = ChainPlan(plan.T, plan.F, abs_events(plan.events), plan.per_channel, plan.n_channels)
+        apply_abs = False
     if rescale_filtrations:
         raise NotImplementedError("Rescaling filtrations within 'get_Batch_Wjxs' has been deprecated.")
     if not torch.is_tensor(x) or x.dim() != 2:
@@ -263,6 +292,8 @@ def get_Batch_Wjxs(
     if plan.per_channel and plan.n_channels != x.shape[1]:
         raise IndexError("index out of range: per-channel diffusion_scales rows != channels of x")
     W = bank(x, op, plan)
+    if apply_abs:                       # with a gradient to x: the signed bank from the kernel, |.| by autograd
+        W = W.abs()
     if not plan.per_channel and plan.T >= 0 and filter_stack_dim not in (-1, 2) \
             and not (diffusion_scales is None and scales_type is None):
         W = W.movedim(-1, filter_stack_dim)

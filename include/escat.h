@@ -58,6 +58,12 @@ extern "C" {
 #define ESCAT_MAX_SLOTS    160  /* F: output slots of a chain (the all-powers plan of infogain uses T+1) */
 
 typedef struct { int32_t step, slot, sign, chan; } escat_event;
+/* Optional |.| epilogue (forward entry points only; OFF in the drop-in path: ESCGNNModular._scatter keeps the signed
+ * coefficients, models/escgnn_modular.py:326-341 -- the modulus exists only in LEGS-style callers,
+ * models/comparisons/legs.py:299-302).  Adding ESCAT_EVENT_ABS to the `sign` of the LAST event of a slot
+ * (sign = +1 + ESCAT_EVENT_ABS or -1 + ESCAT_EVENT_ABS) makes the chain keep |value| in that slot once the event
+ * has been applied, in the same pass; the backward entry points reject it. */
+#define ESCAT_EVENT_ABS    256
 
 /* Packed "SELL-64" copy of a CSR / BSR-3 operator for the register-resident
  * chain kernels (all members are device pointers; the struct itself lives on

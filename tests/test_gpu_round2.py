@@ -1,0 +1,115 @@
+"""
+Round-2 GPU tests: the |.| epilogue flag (ESCAT_EVENT_ABS), the fused-orders guard for rows larger than the LDS tile,
+through the drop-in Python signatures and the C ABI, against the oracle.
+"""
+import ctypes
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(a, ref, rtol=1e-5):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    for f in range(ref.shape[-1]):
+        d = np.abs(a[..., f] - ref[..., f]).max()
+        assert d <= rtol * np.abs(ref[..., f]).max() + 1e-30, (f, d)
+
+
+@pytest.mark.parametrize("shape", ["register", "multi_launch"])
+def test_apply_abs_flag_vs_abs_of_oracle_bank(oracle_lib, shape, monkeypatch):
+    """apply_abs=True (off by default, not a reference argument; the caller shape is models/comparisons/legs.py:299-302)
+    = torch.abs of the oracle's signed bank, on the register-resident path and on the multi-launch path, P and Q,
+    dyadic and custom scales; with a gradient to x the modulus goes through autograd (sign(W) * upstream)."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    dev = _dev()
+    if shape == "multi_launch":
+        monkeypatch.setenv("ESCAT_CHAIN_PATH", "multi")
+    b = synthetic.ellipsoid_batch(6, 150, 6, seed=77)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    x = torch.randn(b["N"], 3, generator=torch.Generator().manual_seed(5))
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    for kw in (dict(scales_type="dyadic", J=3), dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6]))):
+        plan = plan_chain(**kw)
+        ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+        refP = np.abs(co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F))
+        refQ = np.abs(co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F))
+        W = get_Batch_Wjxs(x.to(dev), opP, apply_abs=True, **kw)
+        assert float(W.min()) >= 0.0
+        _close(W, refP)
+        _close(get_Batch_Wjxs(xv.to(dev), opQ, apply_abs=True, **kw), refQ)
+        # the default stays signed (the reference's _scatter keeps signs)
+        assert float(get_Batch_Wjxs(x.to(dev), opP, **kw).min()) < 0.0
+    xg = x.to(dev).requires_grad_(True)
+    Wg = get_Batch_Wjxs(xg, opP, J=3, apply_abs=True)
+    Ws = get_Batch_Wjxs(x.to(dev), opP, J=3)
+    G = torch.randn(Wg.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    (Wg * G).sum().backward()
+    xr = x.to(dev).requires_grad_(True)
+    (get_Batch_Wjxs(xr, opP, J=3) * (G * torch.sign(Ws))).sum().backward()
+    assert torch.equal(xg.grad, xr.grad)
+
+
+def test_abs_event_rejected_by_backward_and_when_not_last():
+    from esc_gnn_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    n = 4
+    rowptr = torch.arange(n + 1, dtype=torch.int32, device=dev)
+    col = torch.arange(n, dtype=torch.int32, device=dev)
+    val = torch.full((n,), 0.5, device=dev)
+    x = torch.ones(n, 1, device=dev)
+    out = torch.empty(n, 1, 1, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def call(fn, events):
+        arr = (_lib.EscatEvent * len(events))()
+        for k, e in enumerate(events):
+            arr[k].step, arr[k].slot, arr[k].sign, arr[k].chan = e
+        ws = torch.empty(64, device=dev)
+        return fn(vp(rowptr), vp(col), vp(val), n, n, vp(x), 1, 1, ctypes.cast(arr, ctypes.c_void_p), len(events), 1, vp(out),
+                  ctypes.c_void_p(0), 0, 0, ctypes.c_void_p(0), vp(ws), 256, ctypes.c_void_p(0))
+    assert call(lib.escat_chain_csr_f32, [(0, 0, 1, -1), (1, 0, -1 + 256, -1)]) == 0
+    torch.cuda.synchronize()
+    assert out.reshape(-1).tolist() == [0.5] * n                       # |x - x/2|
+    assert call(lib.escat_chain_csr_f32, [(0, 0, 1 + 256, -1), (1, 0, -1, -1)]) == -1     # |.| must close the slot
+    assert call(lib.escat_chain_csr_bwd_f32, [(0, 0, 1, -1), (1, 0, -1 + 256, -1)]) == -1  # forward only
+
+
+def test_fused_orders_with_rows_larger_than_the_lds_tile():
+    """C = 1, parts of <= 15 rows and F >= 11 make one output row (1 + F + F(F-1)/2 floats) larger than the
+    LDS tile of the fused orders epilogue; the library rejects it (ESCAT_ERANGE) and scatter() takes the two-kernel
+    form.  Compared with the reference formula on the oracle's bank."""
+    from esc_gnn_amd import scatter, ScatterOperator, synthetic, plan_chain, _lib
+    from esc_gnn_amd.pyg_utilities import _chain_launch, NoFusedOrders
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(40, 8, 3, seed=9)                 # 8-node graphs
+    t = lambda a: torch.from_numpy(a).to(dev)
+    gp = torch.arange(41, dtype=torch.int32, device=dev) * 8
+    opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"],
+                                   parts=ScatterOperator.parts_from_graph_ptr(gp))       # one part per graph: 8 rows
+    scales = torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12])                         # F = 12
+    kw = {"diffusion_kwargs": dict(scales_type="custom", diffusion_scales=scales)}
+    plan = plan_chain(**kw["diffusion_kwargs"])
+    assert plan.F >= 11
+    x = torch.randn(b["N"], 1, generator=torch.Generator().manual_seed(4))
+    with pytest.raises(NoFusedOrders):
+        _chain_launch(opP, plan.events, plan.T, plan.F, x.to(dev), 1, False, orders=2)
+    W = scatter(track="scalar", x0=x.to(dev), P_or_Q=opP, kwargs=kw)                      # falls back to bank + orders
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    bank = co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F)
+    iu = np.triu_indices(plan.F, 1)
+    ref = np.concatenate([x.numpy()[..., None], bank, bank[..., iu[0]] * bank[..., iu[1]]], axis=-1)
+    assert W.shape == ref.shape
+    assert np.abs(W.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
