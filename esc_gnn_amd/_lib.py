@@ -41,6 +41,7 @@ SIGNATURES = {
     "escat_bsr3_spmv_f32": (ci, [vp, vp, vp, i64, i64, vp, vp, vp]),
     "escat_chain_workspace_bytes": (sz, [i64, ci]),
     "escat_chain_csr_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
+    "escat_chain_csr_static_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp]),
     "escat_chain_csr_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_chain_bsr3_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),

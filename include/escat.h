@@ -182,6 +182,22 @@ int escat_chain_csr_f32(const int32_t *rowptr, const int32_t *col, const float *
                         const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* The one entry point that ALLOCATES NOTHING.  It has no counterpart in the reference; it is for callers that cannot
+ * call hipMalloc or pass a workspace they allocated: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation.  Same arguments and results as escat_chain_csr_f32 minus the workspace: when the call takes the
+ * multi-launch path (no part_ptr / parts that do not fit LDS) the two ping-pong vectors live in a static device array
+ * of ESCAT_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.  Calls whose
+ * escat_chain_workspace_bytes(n, C) exceeds that are rejected with ESCAT_ERANGE.  The array's device address is looked
+ * up on the first call on each device (hipGetSymbolAddress; make that call outside graph capture).  All calls on one GPU
+ * share the array: calls that overlap on one GPU (two streams) race; calls on one stream are ordered and safe.  The
+ * vectors are fully written before they are read, so nothing is cleared between calls. */
+#define ESCAT_STATIC_SCRATCH_BYTES (8u << 20)
+int escat_chain_csr_static_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                               int64_t n, int64_t nnz, const float *X, int C, int T,
+                               const escat_event *events, int n_events, int F, float *OUT,
+                               const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
+                               void *stream);
+
 /* Backward of the above w.r.t. X (what autograd of the reference's chain
  * computes when x.requires_grad): dX = sum_events sign * (A^T)^step G[:, chan, slot].
  * Takes the TRANSPOSED operator in CSR (rows of A^T sorted by column) and the
