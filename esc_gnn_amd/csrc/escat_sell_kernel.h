@@ -93,14 +93,15 @@ template <int DMAX> struct OpBsr3 {
     // and without branches in the body the compiler can count them (s_waitcnt lgkmcnt(N), not 0).  The odd slot of a
     // rounded-up width re-reads a real block against the all-zero row.
     __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
-    template <int W>
-    __device__ __forceinline__ void gather_w(const float *xa, vf2 &a01, vf2 &t2, float &a2) const
+    template <int W, class Mid>
+    __device__ __forceinline__ void gather_w(const float *xa, vf2 &a01, vf2 &t2, float &a2, Mid mid) const
     {
         constexpr int D = RING;
         vf4 xv[D];
         const unsigned base = lds_addr(xa);
 #pragma unroll
         for (int d = 0; d < D && d < W; ++d) lds_gather(xv[d], base + row_of(d) * 16u);   // a row is 4 floats
+        mid();                                    // work that needs no gather result runs under the first gathers' latency
 #pragma unroll
         for (int d = 0; d < W; ++d) {
             // gather d has landed once at most min(D-1, W-1-d) younger ones are outstanding (LDS returns in order)
@@ -126,19 +127,20 @@ template <int DMAX> struct OpBsr3 {
             }
         }
     }
-    template <int W>
-    __device__ __forceinline__ void dispatch(int w2, const float *xa, vf2 &a01, vf2 &t2, float &a2) const
+    template <int W, class Mid>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, vf2 &a01, vf2 &t2, float &a2, Mid mid) const
     {
         if constexpr (W <= DMAX) {
-            if (w2 == W / 2) gather_w<W>(xa, a01, t2, a2);
-            else dispatch<W + 2>(w2, xa, a01, t2, a2);
+            if (w2 == W / 2) gather_w<W>(xa, a01, t2, a2, mid);
+            else dispatch<W + 2>(w2, xa, a01, t2, a2, mid);
         }
     }
-    __device__ __forceinline__ void gather(const float *xa, int w, float (&a)[3]) const
+    template <class Mid>
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&a)[3], Mid mid) const
     {
         vf2 a01 = {0.f, 0.f}, t2 = {0.f, 0.f};    // (y0, y1) and the two-column partial sums of y2
         float a2 = 0.f;
-        dispatch<2>((w + 1) >> 1, xa, a01, t2, a2);
+        dispatch<2>((w + 1) >> 1, xa, a01, t2, a2, mid);
         a[0] += a01.x; a[1] += a01.y; a[2] += a2 + (t2.x + t2.y);
     }
     static __device__ __forceinline__ void tail(const float *__restrict__ blk, const int *__restrict__ col, int e0, int n,
@@ -174,8 +176,8 @@ template <int CC, int DMAX> struct OpCsr {
     }
     __device__ __forceinline__ unsigned row_of(int d) const { return (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu); }
     static constexpr int RING = CC <= 4 ? 6 : 3;  // gathers in flight per lane (CP / 4 or 2 x 4 VGPRs each)
-    template <int W>
-    __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[CC]) const      // see OpBsr3::gather_w
+    template <int W, class Mid>
+    __device__ __forceinline__ void gather_w(const float *xa, float (&acc)[CC], Mid mid) const      // see OpBsr3::gather_w
     {
         constexpr int D = RING;
         constexpr int PER = CP == 8 ? 2 : 1;     // LDS operations per gather
@@ -187,6 +189,7 @@ template <int CC, int DMAX> struct OpCsr {
             lds_gather(xv[d][0], base + row_of(d) * (unsigned)(CP * 4));
             if (PER == 2) lds_gather(xv[d][PER - 1], base + row_of(d) * (unsigned)(CP * 4) + 16u);
         }
+        mid();
 #pragma unroll
         for (int d = 0; d < W; ++d) {
             const int later = (W - 1 - d < D - 1 ? W - 1 - d : D - 1) * PER;     // younger LDS operations still allowed in flight
@@ -218,15 +221,16 @@ template <int CC, int DMAX> struct OpCsr {
             }
         }
     }
-    template <int W>
-    __device__ __forceinline__ void dispatch(int w2, const float *xa, float (&acc)[CC]) const
+    template <int W, class Mid>
+    __device__ __forceinline__ void dispatch(int w2, const float *xa, float (&acc)[CC], Mid mid) const
     {
         if constexpr (W <= DMAX) {
-            if (w2 == W / 2) gather_w<W>(xa, acc);
-            else dispatch<W + 2>(w2, xa, acc);
+            if (w2 == W / 2) gather_w<W>(xa, acc, mid);
+            else dispatch<W + 2>(w2, xa, acc, mid);
         }
     }
-    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[CC]) const { dispatch<2>((w + 1) >> 1, xa, acc); }
+    template <class Mid>
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[CC], Mid mid) const { dispatch<2>((w + 1) >> 1, xa, acc, mid); }
     static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
                                                 int gs, const float *xa, float (&acc)[CC])
     {
@@ -303,7 +307,8 @@ template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
             else dispatch<W + 2>(w2, xa, acc);
         }
     }
-    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[3]) const { dispatch<2>((w + 1) >> 1, xa, acc); }
+    template <class Mid>
+    __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[3], Mid mid) const { mid(); dispatch<2>((w + 1) >> 1, xa, acc); }
     static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
                                                 int gs, const float *xa, float (&acc)[3])
     {
@@ -537,6 +542,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
             rtN = lm[0]; te0N = lm[1]; swN = lm[2];
         }
         bool staged = !(has_next && (!BWD || early));   // "nothing to stage early"
+        int pq0 = 0, pq1 = 0;                     // forward: events of the previous step, applied under this step's first gathers
         for (int t = 1; t <= T; ++t) {
             int q0, q1;
             step_range<BWD>(tab, BWD ? T - t : t, p, q0, q1);
@@ -546,7 +552,15 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
 #ifdef ESCAT_STAMPS
             if (t == 5) { STAMPW(li, 8, 0); STAMPW(li, 12, NT - 64); }
 #endif
-            op.gather(xa, w, acc);
+            // The slab bookkeeping of step t-1 (this thread's own slab rows, its own y re-read from its row of xa) needs
+            // nothing from this step: it runs while the first gathers are in flight instead of ahead of the barrier.
+            op.gather(xa, w, acc, [&]() {
+                if (!BWD && own && pq1 > pq0) {
+                    XVec<CP> yp; yp.load(xa + r * CP);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) apply_events<false>(tab, pq0, pq1, c, yp.v[c], slab + (r * C + c) * Fs + so);
+                }
+            });
 #ifdef ESCAT_STAMPS
             if (t == 5) { STAMPW(li, 9, 0); STAMPW(li, 13, NT - 64); }
 #endif
@@ -555,10 +569,20 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 XVec<CP> y;
 #pragma unroll
                 for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
+                if (BWD) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) y.v[c] = apply_events<BWD>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
+                    for (int c = 0; c < C; ++c) y.v[c] = apply_events<true>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) y.v[c] = acc[c];
+                }
                 y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
+                if (!BWD && t == T) {             // the last step has no successor to hide behind
+#pragma unroll
+                    for (int c = 0; c < C; ++c) apply_events<false>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
+                }
             }
+            pq0 = q0; pq1 = (!BWD && t < T) ? q1 : q0;
 #ifdef ESCAT_STAMPS
             if (t == 5) { STAMPW(li, 10, 0); STAMPW(li, 14, NT - 64); }
 #endif
