@@ -242,7 +242,7 @@ __device__ void jacobi3(double A[3][3], double V[3][3], double ev[3])
 __global__ void __launch_bounds__(256)
 k_local_frames(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ pos, int64_t n,
                int kernel, float eps, int has_eps, float r_cut, int has_rcut, int take_sqrt, int mean_recenter,
-               float *__restrict__ frames, int *__restrict__ n_isolated)
+               float *__restrict__ frames, int *__restrict__ n_isolated, int tikhonov, float tikhonov_eps)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -274,6 +274,10 @@ k_local_frames(const int *__restrict__ rowptr, const int *__restrict__ col, cons
         M[1][1] += uy * uy; M[1][2] += uy * uz; M[2][2] += uz * uz;
     }
     M[1][0] = M[0][1]; M[2][0] = M[0][2]; M[2][1] = M[1][2];
+    // rank_deficiency_strategy='Tikhonov' (process_pyg_data.py:262-279): a neighbourhood of fewer than d = 3 points takes
+    // the eigenvectors of C C^T + eps I, descending.  (The shift changes no Jacobi rotation angle: the frame of such a
+    // node is its data-driven direction(s) completed by the solver's basis of the degenerate complement.)
+    if (tikhonov && cnt < 3) { M[0][0] += (double)tikhonov_eps; M[1][1] += (double)tikhonov_eps; M[2][2] += (double)tikhonov_eps; }
     double V[3][3], ev[3];
     jacobi3(M, V, ev);
     for (int a = 0; a < 3; ++a)
@@ -370,18 +374,29 @@ extern "C" int escat_build_knn_P(const float *pos, const int32_t *graph_ptr, int
     return ESCAT_OK;
 }
 
-extern "C" int escat_build_frames(const int32_t *rowptr, const int32_t *col, const float *pos, int64_t n_nodes,
-                                  int kernel, float gaussian_eps, int has_eps, float r_cut, int has_rcut, int take_sqrt,
-                                  int mean_recenter, float *frames, int32_t *n_isolated, void *stream)
+extern "C" int escat_build_frames_ex(const int32_t *rowptr, const int32_t *col, const float *pos, int64_t n_nodes,
+                                     int kernel, float gaussian_eps, int has_eps, float r_cut, int has_rcut, int take_sqrt,
+                                     int mean_recenter, int tikhonov, float tikhonov_eps, float *frames, int32_t *n_isolated,
+                                     void *stream)
 {
     if (!rowptr || !col || !pos || !frames || !n_isolated) return fail(ESCAT_EINVAL, "NULL pointer");
     if (kernel < 0 || kernel > 2) return fail(ESCAT_EINVAL, "kernel must be 0 (gaussian), 1 (cosine_cutoff) or 2 (epanechnikov)");
     if (kernel != 0 && !has_rcut) return fail(ESCAT_EINVAL, "r_cut must be provided for cutoff kernels");
+    if (tikhonov && !(tikhonov_eps >= 0.f)) return fail(ESCAT_EINVAL, "tikhonov_eps must be >= 0");
     if (n_nodes <= 0) return n_nodes == 0 ? ESCAT_OK : fail(ESCAT_EINVAL, "negative size");
     hipLaunchKernelGGL(k_local_frames, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, S(stream), rowptr, col, pos, n_nodes,
-                       kernel, gaussian_eps, has_eps, r_cut, has_rcut, take_sqrt, mean_recenter, frames, n_isolated);
+                       kernel, gaussian_eps, has_eps, r_cut, has_rcut, take_sqrt, mean_recenter, frames, n_isolated,
+                       tikhonov, tikhonov_eps);
     CHECK_LAUNCH("escat_build_frames");
     return ESCAT_OK;
+}
+
+extern "C" int escat_build_frames(const int32_t *rowptr, const int32_t *col, const float *pos, int64_t n_nodes,
+                                  int kernel, float gaussian_eps, int has_eps, float r_cut, int has_rcut, int take_sqrt,
+                                  int mean_recenter, float *frames, int32_t *n_isolated, void *stream)
+{
+    return escat_build_frames_ex(rowptr, col, pos, n_nodes, kernel, gaussian_eps, has_eps, r_cut, has_rcut, take_sqrt,
+                                 mean_recenter, 0, 0.f, frames, n_isolated, stream);
 }
 
 extern "C" int escat_build_Q_bsr3(const int32_t *rowptr, const int32_t *col, const float *pval, const float *frames,

@@ -213,7 +213,7 @@ class H5Reader:
         self.buf = np.memmap(path, dtype=np.uint8, mode="r")
         b = bytes(self.buf[:48])
         if b[:8] != _SIG or b[8] != 2:
-            raise ValueError("not an HDF5 file with a version-2 superblock")
+            raise ValueError("not an HDF5 file with a version-2 superblock (classic files: hdf5_min.open_h5)")
         if struct.unpack("<I", b[44:48])[0] != lookup3(b[:44]):
             raise ValueError("superblock checksum mismatch")
         self.eof, self.root = struct.unpack("<QQ", b[28:44])
@@ -315,6 +315,27 @@ class _Dataset:
             return np.zeros(self.shape, self.dtype)[idx]
         raw = np.frombuffer(bytes(self.f.buf[self.addr:self.addr + self.size]), dtype=self.dtype)
         return raw.reshape(self.shape)[idx]
+
+
+def open_h5(path: str):
+    """reader for either kind of file: the version-2 files this module writes (H5Reader) or the classic files h5py /
+    libhdf5 write by default -- superblock 0/1, symbol-table groups, chunked + gzip datasets, i.e. what the reference's
+    own writers produce (hdf5_classic.ClassicH5Reader).  Same surface: f["P"]["0"]["indices"][...]."""
+    with open(path, "rb") as fh:
+        head = fh.read(8 + 1)
+        off = 0
+        while head[:8] != _SIG:
+            off = 512 if off == 0 else off * 2
+            fh.seek(off)
+            head = fh.read(9)
+            if len(head) < 9:
+                raise ValueError(f"{path}: no HDF5 signature")
+    if head[8] in (0, 1):
+        from .hdf5_classic import ClassicH5Reader
+        return ClassicH5Reader(path)
+    if off != 0:
+        raise ValueError(f"{path}: version-{head[8]} superblock behind a user block is not supported")
+    return H5Reader(path)
 
 
 # ------------------------------------------------------------------ the reference's operator file

@@ -59,10 +59,12 @@ class EdgeGroups:
 
 def edge_groups(edge_index: torch.Tensor, n_nodes: int) -> EdgeGroups:
     eg = getattr(edge_index, "_escat_groups", None)
-    if eg is None or eg.n_nodes != n_nodes or eg.n_edges != int(edge_index.shape[1]):
+    if eg is None or eg.n_nodes != n_nodes or eg.n_edges != int(edge_index.shape[1]) \
+            or getattr(edge_index, "_escat_groups_version", -1) != edge_index._version:      # edited in place since
         eg = EdgeGroups(edge_index, n_nodes)
         try:
             edge_index._escat_groups = eg
+            edge_index._escat_groups_version = edge_index._version
         except Exception:
             pass
     return eg

@@ -746,15 +746,32 @@ class FactoredVectorOperator:
         return FactoredVectorOperator(frames, ScatterOperator.from_csr(rowptr, col, val3.contiguous(), n, validate=False, parts=parts))
 
 
+def _tensor_versions(A):
+    """version counters of a sparse tensor's components (in-place edits through the tensor's own values/indices bump them)"""
+    try:
+        if A.layout == torch.sparse_coo:
+            return (A._values()._version, A._indices()._version)
+        if A.layout == torch.sparse_csr:
+            return (A.values()._version, A.col_indices()._version, A.crow_indices()._version)
+    except Exception:
+        pass
+    return None
+
+
 def as_operator(P_sparse):
-    """torch sparse tensor (or a ScatterOperator) -> ScatterOperator, cached on the tensor object."""
+    """torch sparse tensor (or a ScatterOperator) -> ScatterOperator, cached on the tensor object together with the
+    version counters of its values / indices: an in-place edit of the operator after the first call rebuilds the pack."""
     if isinstance(P_sparse, (ScatterOperator, OperatorBatch, FactoredVectorOperator)):
         return P_sparse
     op = getattr(P_sparse, "_escat_operator", None)
+    ver = _tensor_versions(P_sparse)
+    if op is not None and getattr(P_sparse, "_escat_versions", ver) != ver:
+        op = None
     if op is None:
         op = ScatterOperator.from_torch(P_sparse)
         try:
             P_sparse._escat_operator = op
+            P_sparse._escat_versions = ver
         except Exception:
             pass
     return op

@@ -11,13 +11,15 @@ scripts/python/generate_ellipsoid_dataset.py:1165-1183).
   process_pyg_data(data, ...)              the reference's signature for ONE graph; returns the same nested dict
                                            (return_data_object=False) or an object carrying sparse P and Q.
 
-Kernel steps and their reference lines are listed in include/escat.h.  Not reproduced: 'radius' graph construction
-(torch-cluster's neighbour cap is unpinned), rank_deficiency_strategy='Tikhonov' (k_i < d neighbourhoods), Bessel
-edge features and Dirac selection (QM9 path, out of scope): these raise NotImplementedError.
+Kernel steps and their reference lines are listed in include/escat.h.  Graph construction: 'k-nn' (the default, with the
+Gaussian RBF x cosine-cutoff edge weights of build_weighted_radius_adjacency, :173-232), 'radius' (all neighbours inside
+r_cutoff among the max_num_neighbors <= 32 nearest -- torch-cluster's choice of WHICH neighbours survive its cap is
+unpinned; identical whenever the cap is not reached), 'reweight_existing_edges', or None (a given edge_index).
+rank_deficiency_strategy='Tikhonov' is supported (:262-279).  Not reproduced: Bessel edge features and Dirac selection
+(QM9 path, out of scope) and custom kernel callables: these raise NotImplementedError.
 """
 import ctypes
 import math
-from types import SimpleNamespace
 from typing import Any, Dict, Optional
 import torch
 
@@ -41,7 +43,7 @@ def _kernel_args(kw: Dict[str, Any]):
 
 
 def frames_and_Q(rowptr, col, pval, pos, kernel_kwargs, use_mean_recentering=False, enforce_sign=True,
-                 sing_vect_align_method="column_dot"):
+                 sing_vect_align_method="column_dot", tikhonov_eps: Optional[float] = None):
     """B2 + B3 on a given CSR pattern (diagonal included) and its P values; returns (frames (N,3,3), blk (nnz,3,3))."""
     lib = _lib.load()
     dev = pos.device
@@ -53,8 +55,9 @@ def frames_and_Q(rowptr, col, pval, pos, kernel_kwargs, use_mean_recentering=Fal
     kid, eps, has_eps, rc, has_rc, sq = _kernel_args(kernel_kwargs)
     with torch.cuda.device(dev):
         st = _stream(dev)
-        _lib.check(lib.escat_build_frames(_ptr(rowptr), _ptr(col), _ptr(pos), n, kid, eps, has_eps, rc, has_rc, sq,
-                                          int(bool(use_mean_recentering)), _ptr(frames), _ptr(iso), st), "escat_build_frames")
+        _lib.check(lib.escat_build_frames_ex(_ptr(rowptr), _ptr(col), _ptr(pos), n, kid, eps, has_eps, rc, has_rc, sq,
+                                             int(bool(use_mean_recentering)), int(tikhonov_eps is not None),
+                                             float(tikhonov_eps or 0.0), _ptr(frames), _ptr(iso), st), "escat_build_frames_ex")
         _lib.check(lib.escat_build_Q_bsr3(_ptr(rowptr), _ptr(col), _ptr(pval), _ptr(frames), n, int(bool(enforce_sign)),
                                           int(sing_vect_align_method == "procrustes"), _ptr(blk), st), "escat_build_Q_bsr3")
     if int(iso.item()):
@@ -79,8 +82,11 @@ def build_PQ_batch(pos: torch.Tensor, graph_ptr: torch.Tensor, k: int, local_pca
     pos = pos.to(torch.float32).contiguous()
     graph_ptr = graph_ptr.to(device=dev, dtype=torch.int32).contiguous()
     N, B = pos.shape[0], graph_ptr.numel() - 1
+    true_max = int((graph_ptr[1:] - graph_ptr[:-1]).max()) if B > 0 else 0
     if max_graph_nodes is None:
-        max_graph_nodes = int((graph_ptr[1:] - graph_ptr[:-1]).max())
+        max_graph_nodes = true_max
+    elif max_graph_nodes < true_max:                   # it sizes the kernels' LDS bitmap: too small would overflow LDS
+        raise ValueError(f"escat: max_graph_nodes={max_graph_nodes} but the largest graph has {true_max} nodes")
     cap = N * (2 * k + 1)
     rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
     col = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -173,8 +179,8 @@ def process_pyg_data(
     if local_pca_kernel_fn is not None:
         raise NotImplementedError("escat: custom local_pca_kernel_fn callables cannot run inside the kernel; "
                                   "use local_pca_kernel_fn_kwargs with kernel = gaussian | cosine_cutoff | epanechnikov")
-    if rank_deficiency_strategy is not None:
-        raise NotImplementedError("escat: rank_deficiency_strategy is not implemented")
+    if rank_deficiency_strategy is not None and str(rank_deficiency_strategy).lower() != 'tikhonov':
+        rank_deficiency_strategy = None                 # the reference only acts on 'Tikhonov' (:262-263) and ignores the rest
     if num_edge_features or include_diracs:
         raise NotImplementedError("escat: Bessel edge features / Dirac selection are outside the scattering hot path")
     if not torch.cuda.is_available():
@@ -188,42 +194,62 @@ def process_pyg_data(
     edge_weight = getattr(data, "edge_weight", None)
     A_vals = None
     if graph_construction is not None:
-        if graph_construction != 'k-nn':
-            raise NotImplementedError("escat: only 'k-nn' graph construction (or None with a given edge_index)")
-        k = int(graph_construction_kwargs['max_num_neighbors'])
-        gp = torch.tensor([0, n], dtype=torch.int32, device=dev)
-        b = build_PQ_batch(v, gp, k, {'kernel': 'gaussian'})       # pattern only; values redone below with weights
-        rp = b["rowptr"].long()
-        rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
-        cols = b["col"].long()
-        off = rows != cols
-        edge_index = torch.stack([rows[off], cols[off]])
+        gck = graph_construction_kwargs
+        if graph_construction in ('k-nn', 'radius'):
+            k = int(gck.get('max_num_neighbors', 32))
+            if k > 32:
+                raise NotImplementedError("escat: max_num_neighbors > 32 is beyond the kNN kernel")
+            gp = torch.tensor([0, n], dtype=torch.int32, device=dev)
+            b = build_PQ_batch(v, gp, min(k, max(n - 1, 1)), {'kernel': 'gaussian'})   # pattern only; values redone below with weights
+            rp = b["rowptr"].long()
+            rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+            cols = b["col"].long()
+            off = rows != cols
+            edge_index = torch.stack([rows[off], cols[off]])        # symmetrised, row-major sorted: to_undirected's order
+            if graph_construction == 'radius':
+                # radius_graph(pos, r_cutoff, max_num_neighbors) + to_undirected (:207-214): of the (at most)
+                # max_num_neighbors nearest, those inside the cutoff; an edge survives if either end keeps it
+                dd = (v[edge_index[0]] - v[edge_index[1]]).norm(dim=1)
+                edge_index = edge_index[:, dd <= float(gck['r_cutoff'])]
+        elif graph_construction == 'reweight_existing_edges':
+            edge_index = get('edge_index').to(dev)
+        else:
+            raise NotImplementedError(f"escat: graph_construction={graph_construction!r}")
         # Gaussian RBF x cosine cutoff weights (build_weighted_radius_adjacency, :217-223)
         dists = (v[edge_index[0]] - v[edge_index[1]]).norm(dim=1)
-        gauss = torch.exp(-((dists / graph_construction_kwargs['gaussian_eps']) ** 2))
-        cosine_cut = 0.5 * (torch.cos(math.pi * dists / graph_construction_kwargs['r_cutoff']) + 1.0)
+        gauss = torch.exp(-((dists / gck['gaussian_eps']) ** 2))
+        cosine_cut = 0.5 * (torch.cos(math.pi * dists / gck['r_cutoff']) + 1.0)
         edge_weight = gauss * cosine_cut
         try:
             data.edge_index, data.edge_weight = edge_index, edge_weight
         except Exception:
-            pass
+            try:
+                data['edge_index'], data['edge_weight'] = edge_index, edge_weight
+            except Exception:
+                pass
     else:
         edge_index = get('edge_index')
     rowptr, col, pval, A = _get_P_csr(edge_index, n, edge_weight, row_normalize, dev)
     if graph_construction is not None:
         A_vals = A.values()
     _, blk = frames_and_Q(rowptr, col, pval, v, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
-                          sing_vect_align_method)
+                          sing_vect_align_method, tikhonov_eps if rank_deficiency_strategy is not None else None)
     batch = {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk,
              "graph_ptr": torch.tensor([0, n], dtype=torch.int32)}
     parts = coo_parts(batch, 0, hdf5_tensor_dtype if not return_data_object else "float32")
     if return_data_object:
         P = torch.sparse_coo_tensor(parts["P"]["indices"], parts["P"]["values"], (n, n)).coalesce()
         Q = torch.sparse_coo_tensor(parts["Q"]["indices"], parts["Q"]["values"], (3 * n, 3 * n))
-        out = SimpleNamespace(**{k_: get(k_) for k_ in (data.keys() if hasattr(data, "keys") else [])})
+        # an ESCGNNData (:870-882) carrying every attribute of `data` plus the operators; P and Q are the reference's
+        # torch sparse tensors, with the canonical device form already attached (get_Batch_Wjxs skips the ingest)
+        from .data_classes import ESCGNNData
+        keys = list(data.keys()) if hasattr(data, "keys") else [k_ for k_ in vars(data) if not k_.startswith("_")]
+        out = ESCGNNData(**{k_: get(k_) for k_ in keys if k_ not in ("P", "Q")})
+        if graph_construction is not None:
+            out.edge_index, out.edge_weight = edge_index, A_vals
+        P._escat_operator = ScatterOperator.from_csr(rowptr, col, pval, n, validate=False)
+        Q._escat_operator = ScatterOperator.from_bsr3(rowptr, col, blk, n, validate=False)
         out.P, out.Q = P, Q
-        out.P._escat_operator = ScatterOperator.from_csr(rowptr, col, pval, n, validate=False)
-        out.Q._escat_operator = ScatterOperator.from_bsr3(rowptr, col, blk, n, validate=False)
         return out
     parts["original_idx"] = data_i
     if graph_construction is not None:

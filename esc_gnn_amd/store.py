@@ -15,7 +15,10 @@ def load_operator_store(path: str, device, indices: Optional[Sequence[int]] = No
                         factored: bool = False) -> Dict:
     """
     Reads the reference's HDF5 operator layout (/{P,Q}/{idx}/{indices,values,size},
-    scripts/python/generate_ellipsoid_dataset.py:1185-1206) for the samples `indices` (default: all, in numeric order)
+    scripts/python/generate_ellipsoid_dataset.py:1185-1206) -- both the version-2 files esc_gnn_amd.hdf5_min writes and
+    the classic files h5py writes (superblock 0, symbol-table groups, chunked + gzip: esc_gnn_amd.hdf5_classic, written
+    from the format specification; no HDF5 library is available here to cross-check: parity unpinned) -- for the
+    samples `indices` (default: all, in numeric order)
     and returns {"P": ScatterOperator, "Q": ScatterOperator, "graph_ptr": int64 (B+1,) node offsets, "ids": list}.
     Values stored as fp16 are widened to fp32 as the reference loader does (escgnn_data_classes.py:137-142).
     The operators carry one part per sample; with pack=True the SELL packs of all four forms are built now.
@@ -24,8 +27,8 @@ def load_operator_store(path: str, device, indices: Optional[Sequence[int]] = No
     stored Q to fp32 rounding only if the file holds fp32 values: fp16 storage rounds every Q entry on its own, which no
     factorisation reproduces (the factored operator is then the closer one to the operator before rounding).
     """
-    from .hdf5_min import H5Reader
-    f = H5Reader(path)
+    from .hdf5_min import open_h5
+    f = open_h5(path)
     try:
         ids = sorted((int(k) for k in f["P"].keys())) if indices is None else [int(i) for i in indices]
         out = {}

@@ -11,16 +11,19 @@ inputs; it is input generation, not part of the measured path.
 import numpy as np
 
 
-def ellipsoid_clouds(B, n, seed=457892, mu=(3.0, 1.0, 1.0), sd=(0.5, 0.2, 0.2)):
-    """(B, n, 3) float32; one RandomState stream, graph after graph, like the reference generator."""
+def ellipsoid_clouds(B, n, seed=457892, mu=(3.0, 1.0, 1.0), sd=(0.5, 0.2, 0.2), dtype=np.float32):
+    """(B, n, 3); one RandomState stream, graph after graph: the draws AND the arithmetic order of the reference's
+    EllipsoidPointCloudGenerator.generate_ellipsoid_points_with_params (ellipsoid_data_classes.py:112-131: semi-axes
+    |N(mu, sd)|, phi, theta, unit-sphere point, then the scaling), computed in float64 like the reference and cast
+    once -- bit-identical to it (tests/test_host.py, golden generated from the reference class)."""
     rng = np.random.RandomState(seed)
-    out = np.empty((B, n, 3), dtype=np.float32)
+    out = np.empty((B, n, 3), dtype=dtype)
     for g in range(B):
         a = abs(rng.normal(mu[0], sd[0])); b = abs(rng.normal(mu[1], sd[1])); c = abs(rng.normal(mu[2], sd[2]))
         phi = rng.uniform(0, 2 * np.pi, n)
         theta = np.arccos(2 * rng.uniform(0, 1, n) - 1)
-        out[g, :, 0] = a * np.sin(theta) * np.cos(phi)
-        out[g, :, 1] = b * np.sin(theta) * np.sin(phi)
+        out[g, :, 0] = a * (np.sin(theta) * np.cos(phi))
+        out[g, :, 1] = b * (np.sin(theta) * np.sin(phi))
         out[g, :, 2] = c * np.cos(theta)
     return out
 

@@ -266,6 +266,13 @@ int escat_build_frames(const int32_t *rowptr, const int32_t *col, const float *p
                        int kernel, float gaussian_eps, int has_eps, float r_cut, int has_rcut,
                        int take_sqrt, int mean_recenter, float *frames, int32_t *n_isolated, void *stream);
 
+/* The same with the reference's rank_deficiency_strategy='Tikhonov' (get_l_singular_vecs, :262-279): when tikhonov != 0
+ * a node with fewer than 3 neighbours takes the eigenvectors of C_i C_i^T + tikhonov_eps * I, by descending eigenvalue. */
+int escat_build_frames_ex(const int32_t *rowptr, const int32_t *col, const float *pos, int64_t n_nodes,
+                          int kernel, float gaussian_eps, int has_eps, float r_cut, int has_rcut,
+                          int take_sqrt, int mean_recenter, int tikhonov, float tikhonov_eps,
+                          float *frames, int32_t *n_isolated, void *stream);
+
 /* Q blocks on P's pattern (calc_O_ij :454-493, loop :823-857): blk[e] =
  * pval[e] * O_i O_j'^T with O_j' = column-dot sign alignment of O_j to O_i
  * (procrustes = 0) or the reference's Procrustes formula (procrustes = 1);

@@ -81,3 +81,64 @@ def test_corruption_is_detected(tmp_path):
     open(path, "wb").write(raw)
     with pytest.raises(ValueError):
         h5.H5Reader(path)["a"]
+
+
+# ------------------------------------------------------------------ classic files (what h5py / libhdf5 write)
+def test_classic_reader_on_a_real_libhdf5_file():
+    """the only libhdf5-written file in the image: scipy's MATLAB v7.3 test file (512-byte user block, superblock 0,
+    symbol-table root group, version-1 object header, contiguous float64 dataset)."""
+    import os
+    import numpy as np
+    import scipy.io
+    from esc_gnn_amd.hdf5_min import open_h5
+    p = os.path.join(os.path.dirname(scipy.io.__file__), "matlab", "tests", "data", "testhdf5_7.4_GLNX86.mat")
+    if not os.path.exists(p):
+        import pytest
+        pytest.skip("scipy test data not installed")
+    f = open_h5(p)
+    assert list(f.keys()) == ["testdouble"]
+    a = f["testdouble"][...]
+    assert a.shape == (9, 1) and a.dtype == np.float64
+    assert np.allclose(a[:, 0], np.arange(9) * np.pi / 4, rtol=0, atol=1e-15)
+    f.close()
+
+
+def test_classic_reader_on_spec_built_operator_file(tmp_path):
+    """the reference's operator layout as h5py would store it (gzip => chunked + deflate, `size` contiguous; groups as
+    symbol tables with more entries than one symbol node / one B-tree node holds), byte fixture assembled from the
+    format specification by tests/h5_classic_writer.py; with and without a user block."""
+    import numpy as np
+    from tests.h5_classic_writer import write_classic
+    from esc_gnn_amd.hdf5_min import open_h5
+    rng = np.random.RandomState(0)
+    data = {}
+    for i in range(300):                                      # 300 children: several SNODs, a two-level group B-tree
+        nnz = 5 + (i % 7)
+        data[f"P/{i}/indices"] = rng.randint(0, 50, size=(2, nnz)).astype(np.int64)
+        data[f"P/{i}/values"] = rng.rand(nnz).astype(np.float16)
+        data[f"P/{i}/size"] = np.array([50, 50], dtype=np.int64)
+    big = rng.rand(2, 1000).astype(np.float32)                 # 40 chunks of 25 columns: a two-level chunk B-tree
+    data["Q/0/values"] = big
+    data["Q/0/indices"] = rng.randint(0, 1 << 40, size=(2, 77)).astype(np.int64)
+    for ub in (0, 512):
+        path = str(tmp_path / f"classic_{ub}.h5")
+        write_classic(path, data, userblock=ub, chunk_rows=25 if True else None)
+        f = open_h5(path)
+        assert type(f).__name__ == "ClassicH5Reader"
+        assert sorted(f.keys()) == ["P", "Q"] and len(list(f["P"].keys())) == 300
+        for name, arr in data.items():
+            d = f[name]
+            assert d.shape == arr.shape and d.dtype == arr.dtype, name
+            assert np.array_equal(d[...], arr), name
+        assert f["Q"]["0"]["values"].kind == "chunked" and f["P"]["7"]["size"].kind == "contiguous"
+        assert "P" in f and "X" not in f
+        f.close()
+
+
+def test_classic_reader_rejects_garbage(tmp_path):
+    import pytest
+    from esc_gnn_amd.hdf5_min import open_h5
+    p = tmp_path / "x.h5"
+    p.write_bytes(b"not hdf5" * 10)
+    with pytest.raises(ValueError):
+        open_h5(str(p))

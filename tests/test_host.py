@@ -294,3 +294,48 @@ def test_signed_pack_of_per_channel_values(monkeypatch):
     z = _Csr(rowptr, col, torch.zeros(5, 3) * -1.0, 3, parts)
     monkeypatch.delenv("ESCAT_FACTORED_FORMAT")
     assert int(z.signed_pack()[2].sum()) == 0
+
+
+def test_ellipsoid_sampler_bit_identical_to_reference_golden():
+    """synthetic.ellipsoid_clouds restates EllipsoidPointCloudGenerator.generate_ellipsoid_points_with_params
+    (ellipsoid_data_classes.py:82-134) -- same draws, same arithmetic order; golden generated from the reference class
+    (tests/golden/make_round2_goldens.py), seed 457892, 4 x 16 points."""
+    import os
+    import numpy as np
+    from esc_gnn_amd import synthetic
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "round2_goldens.npz"))
+    assert np.array_equal(synthetic.ellipsoid_clouds(4, 16, seed=457892, dtype=np.float64), g["ell_clouds"])
+    assert np.array_equal(synthetic.ellipsoid_clouds(3, 16, seed=457892, dtype=np.float64), g["ell_clouds_own_rng"])
+    assert np.array_equal(synthetic.ellipsoid_clouds(4, 16, seed=457892), g["ell_clouds"].astype(np.float32))
+
+
+def test_escgnn_data_surface():
+    """the object process_pyg_data returns (models/escgnn_data_classes.py:13-39): operator keys collate block-diagonally"""
+    import torch
+    from esc_gnn_amd.data_classes import ESCGNNData
+    d = ESCGNNData(pos=torch.zeros(4, 3), edge_index=torch.zeros(2, 5, dtype=torch.long), P=torch.eye(4).to_sparse())
+    assert d.__cat_dim__("P", d.P) == (0, 1) and d.__cat_dim__("Q", None) == (0, 1)
+    assert d.__cat_dim__("edge_index", d.edge_index) == 1 and d.__cat_dim__("pos", d.pos) == 0
+    assert set(["pos", "edge_index", "P"]) <= set(d.keys()) and d["pos"].shape == (4, 3)
+    d2 = ESCGNNData(operator_keys=("P", "Q", "L"), x=torch.ones(2))
+    assert d2.__cat_dim__("L", None) == (0, 1)
+    assert d.to("cpu") is not None
+
+
+def test_operator_cache_follows_in_place_edits():
+    """as_operator caches the canonical operator on the tensor; an in-place edit of its values rebuilds it."""
+    import torch
+    from esc_gnn_amd import operators
+    A = torch.sparse_coo_tensor(torch.tensor([[0, 0, 1, 1], [0, 1, 0, 1]]), torch.tensor([.5, .5, .5, .5]), (2, 2)).coalesce()
+    calls = []
+    orig = operators.ScatterOperator.from_torch
+    operators.ScatterOperator.from_torch = staticmethod(lambda t, *a, **k: calls.append(1) or orig(t, allow_cpu=True))
+    try:
+        op1 = operators.as_operator(A)
+        assert operators.as_operator(A) is op1 and len(calls) == 1
+        A._values().mul_(2.0)
+        op2 = operators.as_operator(A)
+        assert op2 is not op1 and len(calls) == 2
+        assert float(op2.csr().val.sum()) == 4.0
+    finally:
+        operators.ScatterOperator.from_torch = orig
