@@ -111,6 +111,43 @@ def cpu_baseline(b, n_graphs, n_per_graph, J, threads):
     return n_graphs / dt, dt
 
 
+def bench_cfg3(c, dev, t, args, J=6, reps=3):
+    """secondary, N = 1 only: BASELINE configs[2] -- one cloud (default 2 M points, k = 16), vector track Q (BSR-3),
+    dyadic J = 6 (T = 64).  The graph does not fit LDS: one step kernel per power (k_bsr3_step), the operator streamed
+    from HBM every step, rows relabelled breadth-first once at ingest.  HIP-event times of the whole chain, forward and
+    backward; the step kernel's roofline uses SURVEY 8d's per-step bytes 4(N+1) + 40 nnz + 24 N."""
+    import torch
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain
+    none = (torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    op = ScatterOperator.from_bsr3(t(c["rowptr"]), t(c["col"]), t(c["blk"]), c["N"], parts=none)
+    op.bsr3_t()
+    torch.cuda.synchronize(); ingest_s = time.perf_counter() - t0
+    plan = plan_chain(scales_type="dyadic", J=J)
+    n, nnzb, T, F = c["N"], c["nnz"], plan.T, plan.F
+    xv = t(c["pos"]).reshape(-1, 1).clone().requires_grad_(True)
+    g = torch.randn(3 * n, 1, F, device=dev)
+    tf = tb = 0.0
+    for r in range(reps + 1):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        xv.grad = None
+        e[0].record(); W = get_Batch_Wjxs(xv, op, scales_type="dyadic", J=J); e[1].record(); W.backward(g); e[2].record()
+        torch.cuda.synchronize()
+        if r >= 1:
+            tf += e[0].elapsed_time(e[1]) / reps; tb += e[1].elapsed_time(e[2]) / reps
+    tele = float((W.detach().sum(-1).reshape(-1) - xv.detach().reshape(-1)).abs().max())
+    step_bytes = 4 * (n + 1) + 40 * nnzb + 24 * n
+    return {"workload": f"cfg3: one ellipsoid cloud, {n} points, kNN k=16, Q (BSR-3) dyadic J={J} (T={T}, F={F}), fwd and bwd "
+                        f"chains; multi-launch path (k_bsr3_step), breadth-first relabelling at ingest",
+            "nodes": n, "nnz_blocks": nnzb, "fwd_ms": tf, "bwd_ms": tb, "fwd_ms_per_step": tf / T,
+            "chains_per_s_fwd_bwd": 1e3 / (tf + tb),
+            "roofline": {"bound": "hbm", "kernel": "k_bsr3_step (one diffusion step)", "bytes_per_step": step_bytes,
+                         "achieved": step_bytes / (tf / T * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": step_bytes / (tf / T * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "algorithmic bytes of one step (operator + x in + y out) / (forward chain time / T)"},
+            "telescoping_max_abs_err": tele, "host_knn_s": c["gen_s"], "ingest_and_relabel_s": ingest_s}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +159,8 @@ def main():
     ap.add_argument("--J", type=int, default=4)
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the secondary cfg3 measurement (one large cloud, N = 1 only)")
+    ap.add_argument("--cfg3-nodes", type=int, default=2_000_000)
     ap.add_argument("--gen-workers", type=int, default=-1,
                     help="processes for input generation (-1: up to 16; use 1 under rocprofv3: no fork after GPU init)")
     args = ap.parse_args()
@@ -157,6 +196,13 @@ def main():
     workers = min(16, os.cpu_count() or 1) if args.gen_workers < 0 else args.gen_workers
     b = synthetic.ellipsoid_batch(args.graphs, args.nodes, args.k, seed=457892 + 1 + rank, workers=workers)
     N, nnz = b["N"], b["nnz"]
+    c3 = None
+    if world == 1 and not args.no_cfg3:
+        # secondary workload (BASELINE configs[2]): one connected cloud, kNN k=16 on the host -- like the batch above it
+        # is generated BEFORE the GPU is touched (the kNN forks workers)
+        tg0 = time.perf_counter()
+        c3 = synthetic.single_cloud(args.cfg3_nodes, 16, workers=workers)
+        c3["gen_s"] = time.perf_counter() - tg0
 
     import torch
     import torch.distributed as dist
@@ -329,6 +375,8 @@ def main():
             out["factored_Q_variant"] = {"value": args.graphs * args.steps / dtf, "unit": "graphs/s",
                                          "ms_per_step": dtf / args.steps * 1e3,
                                          "note": "opt-in operator format, not the headline; see DESIGN.md (factored vector operator)"}
+        if c3 is not None:
+            out["cfg3"] = bench_cfg3(c3, dev, t, args)
         if not args.no_cpu_baseline and world == 1:
             sample = min(args.cpu_sample_graphs, args.graphs)
             gps1, s1 = cpu_baseline(b, sample, args.nodes, args.J, 1)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--graphs", "64", "--nodes", "128", "--k", "5",
-                        "--steps", "2", "--warmup", "1", "--cpu-sample-graphs", "4", "--gen-workers", "1"],
+                        "--steps", "2", "--warmup", "1", "--cpu-sample-graphs", "4", "--gen-workers", "1", "--cfg3-nodes", "30000"],
                        capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -28,6 +28,9 @@ def test_bench_json_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["frac"] <= 1.0 and "lds" in rf and rf["lds"]["frac"] <= 1.0 and "algorithmic_GBs" in rf
+    c3 = d["cfg3"]
+    assert c3["nodes"] == 30000 and c3["fwd_ms"] > 0 and c3["roofline"]["bound"] == "hbm" and c3["telescoping_max_abs_err"] < 1e-4
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
