@@ -30,7 +30,14 @@ class EscatSell(ctypes.Structure):
                 ("val_planes", ctypes.c_int32),
                 ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p),
                 ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32),
-                ("orders", ctypes.c_int32), ("frames", ctypes.c_void_p)]
+                ("orders", ctypes.c_int32), ("frames", ctypes.c_void_p),
+                ("layout", ctypes.c_int32), ("pos_of_row", ctypes.c_void_p)]
+
+
+class EscatSellDims(ctypes.Structure):
+    _fields_ = [("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("slices_per_part", ctypes.c_int32),
+                ("layout", ctypes.c_int32), ("total_d", ctypes.c_int64), ("total_p", ctypes.c_int64),
+                ("val_floats", ctypes.c_int64), ("lc_words", ctypes.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/escat.h declares
@@ -48,6 +55,10 @@ SIGNATURES = {
     "escat_scatter_orders_f32": (ci, [vp, vp, i64, ci, ci, vp, vp]),
     "escat_scatter_orders_bwd_f32": (ci, [vp, i64, vp, i64, ci, ci, vp, vp, vp]),
     "escat_sell_plan_slots": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]),
+    "escat_sell_pack_workspace_bytes": (sz, [i64, ci]),
+    "escat_sell_pack_plan": (ci, [vp, i64, vp, ci, ci, ci, ci, vp, sz, vp, vp]),
+    "escat_sell_pack_fill": (ci, [vp, vp, vp, vp, i64, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp]),
+    "escat_transpose_sym": (ci, [vp, vp, vp, i64, i64, ci, vp, vp, vp]),
     "escat_neighbor_pool_f32": (ci, [vp, vp, i64, ci, ci, ci, ci, vp, vp, vp, vp]),
     "escat_neighbor_pool_bwd_f32": (ci, [vp, vp, i64, ci, ci, ci, vp, vp, vp, vp]),
     "escat_vector_invariants_f32": (ci, [vp, vp, vp, i64, ci, ci, ci, ci, ci, vp, vp, vp, vp]),

@@ -33,7 +33,7 @@ int escat_fail(int code, const char *fmt, ...)      // shared with escat_build.h
     return code;
 }
 extern "C" const char *escat_last_error(void) { return g_err; }
-extern "C" int escat_abi_version(void) { return 1; }
+extern "C" int escat_abi_version(void) { return 2; }
 
 #ifdef ESCAT_STAMPS
 extern "C" int escat_debug_set_stamps_bsr3(void *), escat_debug_set_stamps_csr12(void *), escat_debug_set_stamps_csr34(void *),
@@ -831,6 +831,8 @@ static int sell_to_dev(const escat_sell *sell, SellDev *sd)
         return fail(ESCAT_EINVAL, "escat_sell.val_planes=%d: 0/1 (one value per entry), 3 (one per channel) or 4 (|value| + sign bits)", sell->val_planes);
     sd->planes = sell->val_planes >= 3 ? sell->val_planes : 1;
     sd->frames = sell->frames;
+    if (sell->layout != 0 && sell->layout != 1) return fail(ESCAT_EINVAL, "escat_sell.layout=%d: 0 or 1", sell->layout);
+    sd->layout = sell->layout; sd->pos_of_row = sell->pos_of_row;
     if (sd->frames && sd->planes < 3) return fail(ESCAT_EINVAL, "escat_sell.frames goes with val_planes = 3");
     return ESCAT_OK;
 }

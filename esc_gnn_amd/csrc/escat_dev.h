@@ -75,6 +75,13 @@ __host__ __device__ __forceinline__ int sell_copyB(int p, int R)
     return (p & ~(blk - 1)) | (lo >> 4) | ((lo & 15) << (m - 4));
 }
 
+// Layout 1 packs (escat_sell.layout, built by escat_pack.hip): an LDS row is a POSITION -- the index, inside the part's
+// workgroup, of the thread that owns the row -- so the owner stores its new vector at its own thread index, and copy B
+// permutes rows inside aligned groups of 16 only: the 8 consecutive lanes of a ds_write_b128 lane group then hit 8
+// distinct 16-byte slots in BOTH copies (conflict-free stores), while a row's bank slot in copy B, (p + 1 + (p >> 5) % 15)
+// & 15, always differs from its slot in copy A (p & 15): the planner keeps its two choices per gather.
+__host__ __device__ __forceinline__ int sell_swzB(int p) { return (p & ~15) | ((p + 1 + ((p >> 5) % 15)) & 15); }
+
 // events of step `st`: [q0, q1) in the table; moves the cursor (fwd: up, bwd: down)
 template <bool BWD>
 __device__ __forceinline__ void step_range(const EvTable &tab, int st, int &p, int &q0, int &q1)
@@ -120,7 +127,10 @@ struct SellDev {
     int orders;                                   // forward only: 0 = the bank; 1 = [x | bank]; 2 = [x | bank | pair products]
     int planes;                                   // CSR packs: 1 = one value per entry, 3 = one per channel (OpCsrV3)
     const float *frames;                          // OpCsrV3 only, optional: (n, 3, 3) local frames; IN and RES are then in
-};                                                // global coordinates (the chain runs D Pt^t D^T instead of Pt^t)
+                                                  // global coordinates (the chain runs D Pt^t D^T instead of Pt^t)
+    int layout;                                   // 0: LDS rows = local rows; 1: LDS rows = owner positions (see sell_swzB)
+    const int *pos_of_row;                        // layout 1: global row -> position (for the streamed tails)
+};
 
 #define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
 #define GATHER_AHEAD 3     // LDS gathers in flight ahead of the FMAs

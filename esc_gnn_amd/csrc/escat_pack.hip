@@ -1,2 +1,351 @@
-// escat_pack.hip -- operator ingest on the GPU (placeholder until the pack kernels land)
+// escat_pack.hip -- operator ingest on the GPU: the SELL-64 pack of the register-resident chain kernels (escat_sell,
+// include/escat.h) and the transposed operator for the backward walk, built by HIP kernels instead of torch index ops
+// (round 1: ~120 lines of sort / scatter calls in esc_gnn_amd/operators.py, 80 ms per 4096-graph batch).
+//
+//   escat_sell_pack_plan   row-length histogram -> capacity dmax; per part: rows ordered by length (stable, descending),
+//                          slice widths; prefix sums of the slices' slot / pair offsets.  Two small read-backs.
+//   escat_sell_pack_fill   one wave per slice: bank-conflict-aware slot + copy planning (as escat_sell_plan_slots),
+//                          then the slice's values, packed LDS rows and lane records written with coalesced stores.
+//   escat_transpose_sym    A^T on A's own pattern when the pattern is symmetric (undirected graphs: P and Q always):
+//                          every entry (i, j) finds (j, i) by binary search in row j.
+//
+// Layouts (escat_sell_dims.layout)
+//   0  LDS rows are the part's local row indices; copy B rotates bits 0-3 to the top of a 256-row block (sell_copyB)
+//   1  LDS rows are POSITIONS = the lane index, inside the part, of the thread that owns the row (rows sorted by
+//      length), copy B swizzles inside 16-row groups (sell_swzB).  The owning thread then stores its new vector row at
+//      its own thread index: both copies' ds_write_b128 are conflict-free (8 consecutive lanes -> 8 distinct 16-B slots),
+//      where layout 0 stores to random rows (~2.6-way conflicts on every store of every step).
 #include "escat_dev.h"
+
+#define PACK_MAX_ROWS 512
+
+// ------------------------------------------------------------------ histogram of row lengths (clamped to 33)
+__global__ void __launch_bounds__(256)
+k_pack_hist(const int *__restrict__ rowptr, int64_t n, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned h[34];
+    if (threadIdx.x < 34) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const int d = rowptr[r + 1] - rowptr[r];
+        atomicAdd(&h[d < 33 ? d : 33], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 34 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ per part: order rows by length, slice widths
+// perm[(part*nsl)*64 + k] = local row at lane position k (-1: none); pos_of_row[gs + r] = k; w[part*nsl + s] = width.
+__global__ void __launch_bounds__(PACK_MAX_ROWS)
+k_pack_order(const int *__restrict__ rowptr, const int *__restrict__ part_ptr, int dmax, int nsl,
+             int *__restrict__ perm, int *__restrict__ pos_of_row, int *__restrict__ w)
+{
+    __shared__ unsigned char key[PACK_MAX_ROWS];
+    const int part = blockIdx.x, gs = part_ptr[part], rows = part_ptr[part + 1] - gs;
+    const int r = threadIdx.x;
+    int d = 0;
+    if (r < rows) { d = rowptr[gs + r + 1] - rowptr[gs + r]; d = d < dmax ? d : dmax; key[r] = (unsigned char)(dmax - d); }
+    __syncthreads();
+    int *pp = perm + (int64_t)part * nsl * 64;
+    if (r < rows) {
+        const int k = key[r];
+        int rank = 0;                              // stable: ties keep row order (torch.argsort(..., stable=True) of round 1)
+        for (int q = 0; q < rows; ++q) { const int kq = key[q]; rank += (kq < k) || (kq == k && q < r); }
+        pp[rank] = r;
+        pos_of_row[gs + r] = rank;
+        if ((rank & 63) == 0) w[part * nsl + (rank >> 6)] = d;      // descending: a slice's first lane has its longest row
+    }
+    for (int k = rows + r; k < nsl * 64; k += PACK_MAX_ROWS) pp[k] = -1;
+    if (r < nsl && r * 64 >= rows) w[part * nsl + r] = 0;
+}
+
+// ------------------------------------------------------------------ exclusive scans over the slices (one workgroup)
+__global__ void __launch_bounds__(1024)
+k_pack_scan(const int *__restrict__ w, int n_slices, int *__restrict__ doff, int *__restrict__ poff)
+{
+    __shared__ long long sd[1024], sp[1024];
+    const int t = threadIdx.x;
+    const int per = (n_slices + 1023) / 1024;
+    const int a = t * per, b = a + per < n_slices ? a + per : n_slices;
+    long long d = 0, p = 0;
+    for (int s = a; s < b; ++s) { d += w[s]; p += ((w[s] + 3) / 4) * 2; }
+    sd[t] = d; sp[t] = p;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long vd = t >= off ? sd[t - off] : 0, vp = t >= off ? sp[t - off] : 0;
+        __syncthreads();
+        sd[t] += vd; sp[t] += vp;
+        __syncthreads();
+    }
+    d = sd[t] - d; p = sp[t] - p;                 // exclusive prefix of this thread's chunk
+    for (int s = a; s < b; ++s) { doff[s] = (int)d; poff[s] = (int)p; d += w[s]; p += ((w[s] + 3) / 4) * 2; }
+    if (t == 1023) { doff[n_slices] = (int)sd[1023]; poff[n_slices] = (int)sp[1023]; }
+}
+
+// ------------------------------------------------------------------ plan + fill, one wave per slice
+// V: floats per entry in `val` (1 scalar, 3 one per channel, 9 a 3x3 block); SIGNED (V == 3 input given as |value| +
+// sign bits): one plane of magnitudes, the three signs in bits 11..13 of the entry's 16-bit LDS-row field.
+template <int V, bool SIGNED, int LAYOUT>
+__global__ void __launch_bounds__(64)
+k_pack_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
+            const int *__restrict__ sign_bits, const int *__restrict__ part_ptr, const int *__restrict__ perm,
+            const int *__restrict__ pos_of_row, const int *__restrict__ doff_, const int *__restrict__ poff_,
+            int dmax, int nsl, float *__restrict__ val_out, unsigned *__restrict__ lc_out, int *__restrict__ lane_meta,
+            int *__restrict__ slot_of_e, int *__restrict__ lc_of_e)
+{
+    __shared__ short cols[64][33];                 // LDS row candidates (copy A) of each lane's kept entries
+    __shared__ signed char ent_of_slot[64][32];    // after planning: which entry sits in slot k (-1: none)
+    __shared__ unsigned short row_of_slot[64][32]; // and the LDS row (copy A or B) it reads
+    __shared__ volatile unsigned long long load[4];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int part = s / nsl;
+    const int gs = part_ptr[part], rows = part_ptr[part + 1] - gs;
+    const int R = sell_padR(rows);
+    const int r = perm[(int64_t)s * 64 + lane];
+    const int doff = doff_[s], poff = poff_[s], w = doff_[s + 1] - doff;
+    int e0 = 0, deg = 0, cnt = 0;
+    if (r >= 0) { e0 = rowptr[gs + r]; deg = rowptr[gs + r + 1] - e0; cnt = deg < dmax ? deg : dmax; }
+    for (int j = 0; j < cnt; ++j) {
+        const int c = col[e0 + j];
+        cols[lane][j] = (short)(LAYOUT == 1 ? pos_of_row[c] : c - gs);
+    }
+    for (int k = 0; k < 32; ++k) { ent_of_slot[lane][k] = -1; row_of_slot[lane][k] = (unsigned short)rows; }
+    unsigned rem = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+    const int l32 = lane & 31;
+    const bool g0 = l32 < 4 || (l32 >= 12 && l32 < 16) || (l32 >= 20 && l32 < 28);
+    const int g = (lane >> 5) * 2 + (g0 ? 0 : 1);
+    int turn = 0;                                  // rank of this lane inside its ds_read_b128 lane group
+    for (int q = 0; q < l32; ++q) {
+        const bool q0 = q < 4 || (q >= 12 && q < 16) || (q >= 20 && q < 28);
+        turn += (q0 == g0);
+    }
+    const unsigned long long gmask32 = g0 ? 0x0FF0F00FULL : 0xF00F0FF0ULL;
+    const unsigned long long gmask = (lane >> 5) ? (gmask32 << 32) : gmask32;
+    const int zslot = rows & 15;
+    for (int k = 0; k < w; ++k) {
+        const bool padded = k >= cnt;
+        const unsigned long long pm = __ballot(padded);
+        if (turn == 0) load[g] = (pm & gmask) ? (1ULL << (4 * zslot)) : 0ULL;
+        for (int t = 0; t < 16; ++t) {
+            if (turn == t && !padded) {
+                unsigned long long L = load[g];
+                int best = 99, bj = 0, bpos = 0;
+                unsigned m = rem;
+                while (m) {
+                    const int j = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int a = cols[lane][j];
+                    const int b = R + (LAYOUT == 1 ? sell_swzB(a) : sell_copyB(a, R));
+                    const int cA = (int)((L >> (4 * (a & 15))) & 15ULL), cB = (int)((L >> (4 * (b & 15))) & 15ULL);
+                    if (cA < best) { best = cA; bj = j; bpos = a; }
+                    if (cB < best) { best = cB; bj = j; bpos = b; }
+                    if (best == 0) break;
+                }
+                if (((L >> (4 * (bpos & 15))) & 15ULL) < 15ULL) L += 1ULL << (4 * (bpos & 15));
+                load[g] = L;
+                ent_of_slot[lane][k] = (signed char)bj;
+                row_of_slot[lane][k] = (unsigned short)bpos;
+                if (slot_of_e) { slot_of_e[e0 + bj] = k; lc_of_e[e0 + bj] = bpos; }
+                rem &= ~(1u << bj);
+            }
+        }
+    }
+    // ---- values: slot-major, every store of the wave one contiguous run
+    constexpr int PER = V == 9 ? 576 : (V == 3 && !SIGNED ? 192 : 64);
+    for (int k = 0; k < w; ++k) {
+        const int j = ent_of_slot[lane][k];
+        float *o = val_out + (int64_t)(doff + k) * PER;
+        if constexpr (V == 9) {
+            float b[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) b[q] = j >= 0 ? val[(int64_t)(e0 + j) * 9 + q] : 0.f;
+            // pieces b00 b10 b01 b11 | b02 b12 b20 b21 | b22   (bij = row i, column j: b[3*i + j])
+            *reinterpret_cast<float4 *>(o + lane * 4) = make_float4(b[0], b[3], b[1], b[4]);
+            *reinterpret_cast<float4 *>(o + 256 + lane * 4) = make_float4(b[2], b[5], b[6], b[7]);
+            o[512 + lane] = b[8];
+        } else if constexpr (V == 3 && !SIGNED) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c * 64 + lane] = j >= 0 ? val[(int64_t)(e0 + j) * 3 + c] : 0.f;
+        } else {
+            o[lane] = j >= 0 ? val[e0 + j] : 0.f;
+        }
+    }
+    // ---- packed LDS rows: pairs cover w rounded up to 4 slots; slots past the row's end read the zero row
+    const int npair = ((w + 3) / 4) * 2;
+    for (int q = 0; q < npair; ++q) {
+        unsigned f[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * q + h;
+            unsigned v = k < 32 ? row_of_slot[lane][k] : (unsigned)rows;
+            if (k >= w) v = (unsigned)rows;
+            if constexpr (SIGNED) {
+                const int j = k < w ? ent_of_slot[lane][k] : -1;
+                if (j >= 0) v |= (unsigned)sign_bits[e0 + j] << 11;
+            }
+            f[h] = v;
+        }
+        lc_out[(int64_t)(poff + q) * 64 + lane] = f[0] | (f[1] << 16);
+    }
+    // ---- the lane's start-up record
+    int *lm = lane_meta + ((int64_t)s * 64 + lane) * 3;
+    const int tail_n = deg > dmax ? deg - dmax : 0;
+    lm[0] = r >= 0 ? (r | (tail_n << 10)) : 0x3ff;
+    lm[1] = r >= 0 ? e0 + dmax : 0;
+    lm[2] = lane == 0 ? doff : lane == 1 ? poff : lane == 2 ? w : lane == 3 ? gs : lane == 4 ? rows : 0;
+}
+
+// ------------------------------------------------------------------ host side
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+// workspace (ints): hist[64] | w[ns] | doff[ns+1] | poff[ns+1] | perm[ns*64] | pos_of_row[n]
+struct PackWs { unsigned *hist; int *w, *doff, *poff, *perm, *pos; };
+static size_t pack_ws_ints(int64_t n, int64_t ns) { return 64 + (size_t)ns + 2 * ((size_t)ns + 1) + (size_t)ns * 64 + (size_t)n + 16; }
+static PackWs pack_ws(void *ws, int64_t n, int64_t ns)
+{
+    int *p = (int *)ws;
+    PackWs o;
+    o.hist = (unsigned *)p; p += 64;
+    o.w = p; p += ns;
+    o.doff = p; p += ns + 1;
+    o.poff = p; p += ns + 1;
+    o.perm = p; p += ns * 64;
+    o.pos = p;
+    return o;
+}
+
+extern "C" size_t escat_sell_pack_workspace_bytes(int64_t n, int n_parts)
+{
+    if (n < 0 || n_parts < 0) return 0;
+    return pack_ws_ints(n, (int64_t)n_parts * 8) * sizeof(int);
+}
+
+extern "C" int escat_sell_pack_plan(const int32_t *rowptr, int64_t n, const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                    int values_per_entry, int layout, void *workspace, size_t workspace_bytes,
+                                    escat_sell_dims *dims, void *stream)
+{
+    if (!rowptr || !part_ptr || !workspace || !dims) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n <= 0 || n_parts <= 0) return fail(ESCAT_EINVAL, "empty operator");
+    if (max_part_rows < 1 || max_part_rows > PACK_MAX_ROWS)
+        return fail(ESCAT_ERANGE, "parts of up to %d rows: the register-resident pack takes at most %d", max_part_rows, PACK_MAX_ROWS);
+    if (values_per_entry != 1 && values_per_entry != 3 && values_per_entry != 9)
+        return fail(ESCAT_EINVAL, "values_per_entry=%d: 1, 3 or 9", values_per_entry);
+    if (layout != 0 && layout != 1) return fail(ESCAT_EINVAL, "layout=%d: 0 or 1", layout);
+    const int nsl = max_part_rows <= 256 ? 4 : 8;
+    const int64_t ns = (int64_t)n_parts * nsl;
+    if (ns >= (1 << 24)) return fail(ESCAT_ERANGE, "%lld slices", (long long)ns);
+    if (workspace_bytes < pack_ws_ints(n, (int64_t)n_parts * 8) * sizeof(int))
+        return fail(ESCAT_EWORKSPACE, "workspace %zu B < %zu B needed", workspace_bytes, pack_ws_ints(n, (int64_t)n_parts * 8) * sizeof(int));
+    PackWs ws = pack_ws(workspace, n, ns);
+    hipStream_t st = S(stream);
+    hipError_t e = hipMemsetAsync(ws.hist, 0, 64 * sizeof(int), st);
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pack_hist, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, n, ws.hist);
+    unsigned hist[34];
+    e = hipMemcpyAsync(hist, ws.hist, sizeof(hist), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "row-length histogram: %s", hipGetErrorString(e));
+    // capacity: the smallest instantiated one that leaves at most 5e-5 of the rows a streamed tail
+    static const int caps1[] = {8, 16, 20, 24, 32}, caps3[] = {8, 16, 20, 24}, caps9[] = {8, 12, 16, 20, 22};
+    const int *caps = values_per_entry == 1 ? caps1 : values_per_entry == 3 ? caps3 : caps9;
+    const int ncap = values_per_entry == 3 ? 4 : 5;
+    const int64_t allowed = (int64_t)(5e-5 * (double)n);
+    int dmax = caps[ncap - 1];
+    for (int i = 0; i < ncap; ++i) {
+        int64_t longer = 0;
+        for (int d = caps[i] + 1; d < 34; ++d) longer += hist[d];
+        if (longer <= allowed) { dmax = caps[i]; break; }
+    }
+    hipLaunchKernelGGL(k_pack_order, dim3(n_parts), dim3(PACK_MAX_ROWS), 0, st, rowptr, part_ptr, dmax, nsl, ws.perm, ws.pos, ws.w);
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, ws.w, (int)ns, ws.doff, ws.poff);
+    int tot[2];
+    e = hipMemcpyAsync(&tot[0], ws.doff + ns, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&tot[1], ws.poff + ns, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "slice offsets: %s", hipGetErrorString(e));
+    CHECK_LAUNCH("escat_sell_pack_plan");
+    dims->dmax = dmax; dims->n_slices = (int32_t)ns; dims->slices_per_part = nsl; dims->layout = layout;
+    dims->total_d = tot[0]; dims->total_p = tot[1];
+    const int per = values_per_entry == 9 ? 576 : values_per_entry == 3 ? 192 : 64;
+    dims->val_floats = ((int64_t)tot[0] + 1) * per;           // + one padding slot (empty slices read it)
+    dims->lc_words = ((int64_t)tot[1] + 1) * 64;              // + one padding pair
+    return ESCAT_OK;
+}
+
+extern "C" int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *sign_bits,
+                                    int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
+                                    const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
+                                    float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
+                                    int32_t *slot_of_e, int32_t *lc_of_e, void *stream)
+{
+    if (!rowptr || !col || !val || !part_ptr || !dims || !workspace || !val_out || !lc_out || !lane_meta_out)
+        return fail(ESCAT_EINVAL, "NULL pointer");
+    if ((slot_of_e != nullptr) != (lc_of_e != nullptr)) return fail(ESCAT_EINVAL, "slot_of_e and lc_of_e go together");
+    if (((uintptr_t)val_out & 15) != 0) return fail(ESCAT_EINVAL, "val_out must be 16-byte aligned");
+    const int64_t ns = dims->n_slices;
+    if (ns != (int64_t)n_parts * dims->slices_per_part) return fail(ESCAT_EINVAL, "dims do not belong to this operator");
+    if (workspace_bytes < pack_ws_ints(n, (int64_t)n_parts * 8) * sizeof(int)) return fail(ESCAT_EWORKSPACE, "workspace too small");
+    if (sign_bits && values_per_entry != 3) return fail(ESCAT_EINVAL, "sign_bits go with values_per_entry = 3 (val = |value|, one per entry)");
+    PackWs ws = pack_ws(workspace, n, ns);
+    hipStream_t st = S(stream);
+    const int per = values_per_entry == 9 ? 576 : (values_per_entry == 3 && !sign_bits) ? 192 : 64;
+    // the padding slot / pair behind the last slice; slot_of_e starts at -1 (entries beyond dmax keep it)
+    hipError_t e = hipMemsetAsync(val_out + dims->total_d * per, 0, (size_t)per * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(lc_out + dims->total_p * 64, 0, 64 * sizeof(uint32_t), st);
+    if (e == hipSuccess && slot_of_e) e = hipMemsetAsync(slot_of_e, 0xff, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t), st);
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+#define GO(VV, SG, LY) hipLaunchKernelGGL((k_pack_fill<VV, SG, LY>), dim3((unsigned)ns), dim3(64), 0, st, rowptr, col, val, sign_bits, \
+        part_ptr, ws.perm, ws.pos, ws.doff, ws.poff, dims->dmax, dims->slices_per_part, val_out, lc_out, lane_meta_out, slot_of_e, lc_of_e)
+    const int ly = dims->layout;
+    if (values_per_entry == 9) { if (ly) GO(9, false, 1); else GO(9, false, 0); }
+    else if (values_per_entry == 1) { if (ly) GO(1, false, 1); else GO(1, false, 0); }
+    else if (sign_bits) { if (ly) GO(3, true, 1); else GO(3, true, 0); }
+    else { if (ly) GO(3, false, 1); else GO(3, false, 0); }
+#undef GO
+    CHECK_LAUNCH("escat_sell_pack_fill");
+    return ESCAT_OK;
+}
+
+// ------------------------------------------------------------------ transpose on a symmetric pattern
+template <int V>
+__global__ void __launch_bounds__(256)
+k_transpose_sym(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val, int64_t n,
+                float *__restrict__ val_t, int *__restrict__ not_symmetric)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const int j = col[e];
+        int lo = rowptr[j], hi = rowptr[j + 1] - 1, at = -1;
+        while (lo <= hi) {                         // rows are sorted by column
+            const int mid = (lo + hi) >> 1, c = col[mid];
+            if (c == (int)i) { at = mid; break; }
+            if (c < (int)i) lo = mid + 1; else hi = mid - 1;
+        }
+        if (at < 0) { atomicOr(not_symmetric, 1); continue; }
+        if constexpr (V == 9) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) val_t[(int64_t)at * 9 + 3 * b + a] = val[(int64_t)e * 9 + 3 * a + b];
+        } else {
+#pragma unroll
+            for (int q = 0; q < V; ++q) val_t[(int64_t)at * V + q] = val[(int64_t)e * V + q];
+        }
+    }
+}
+
+extern "C" int escat_transpose_sym(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
+                                   int values_per_entry, float *val_t, int32_t *not_symmetric, void *stream)
+{
+    if (!rowptr || !col || !val || !val_t || !not_symmetric) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n <= 0 || nnz <= 0) return ESCAT_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (values_per_entry == 1) hipLaunchKernelGGL((k_transpose_sym<1>), dim3(grid), dim3(256), 0, S(stream), rowptr, col, val, n, val_t, not_symmetric);
+    else if (values_per_entry == 3) hipLaunchKernelGGL((k_transpose_sym<3>), dim3(grid), dim3(256), 0, S(stream), rowptr, col, val, n, val_t, not_symmetric);
+    else if (values_per_entry == 9) hipLaunchKernelGGL((k_transpose_sym<9>), dim3(grid), dim3(256), 0, S(stream), rowptr, col, val, n, val_t, not_symmetric);
+    else return fail(ESCAT_EINVAL, "values_per_entry=%d: 1, 3 or 9", values_per_entry);
+    CHECK_LAUNCH("escat_transpose_sym");
+    return ESCAT_OK;
+}

@@ -57,6 +57,7 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) { return (unsigned)
 //   tail(...)                   entries beyond dmax, streamed
 template <int DMAX> struct OpBsr3 {
     static constexpr bool FRAMES = false;
+    static constexpr bool POS = true;             // takes layout-1 packs (LDS rows = owner positions)
     static constexpr int C = 3, CP = 4, MINW = 1;
     static constexpr int RING = 4;                // LDS gathers in flight per lane (4 VGPRs each)
     // a block's 9 floats as the three pieces they are loaded in, ordered for packed fp32 math:
@@ -144,11 +145,11 @@ template <int DMAX> struct OpBsr3 {
         a[0] += a01.x; a[1] += a01.y; a[2] += a2 + (t2.x + t2.y);
     }
     static __device__ __forceinline__ void tail(const float *__restrict__ blk, const int *__restrict__ col, int e0, int n,
-                                                int gs, const float *xa, float (&a)[3])
+                                                int gs, const float *xa, float (&a)[3], const int *__restrict__ pos)
     {
         for (int e = e0; e < e0 + n; ++e) {       // rows longer than the pack: from L2, every step
             const float *bb = blk + (int64_t)e * 9;
-            const float *x = xa + (col[e] - gs) * 4;
+            const float *x = xa + (pos ? pos[col[e]] : col[e] - gs) * 4;
             const float x0 = x[0], x1 = x[1], x2 = x[2];
             a[0] = fmaf(bb[0], x0, a[0]); a[0] = fmaf(bb[1], x1, a[0]); a[0] = fmaf(bb[2], x2, a[0]);
             a[1] = fmaf(bb[3], x0, a[1]); a[1] = fmaf(bb[4], x1, a[1]); a[1] = fmaf(bb[5], x2, a[1]);
@@ -160,6 +161,7 @@ template <int DMAX> struct OpBsr3 {
 template <int CC, int DMAX> struct OpCsr {
     static_assert(DMAX % 2 == 0, "DMAX must be even (packed LDS rows)");
     static constexpr bool FRAMES = false;
+    static constexpr bool POS = true;
     static constexpr int C = CC, CP = CC == 1 ? 1 : (CC == 2 ? 2 : (CC <= 4 ? 4 : 8));
     static constexpr int MINW = 4;                // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
     float v[DMAX];
@@ -232,11 +234,11 @@ template <int CC, int DMAX> struct OpCsr {
     template <class Mid>
     __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[CC], Mid mid) const { dispatch<2>((w + 1) >> 1, xa, acc, mid); }
     static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
-                                                int gs, const float *xa, float (&acc)[CC])
+                                                int gs, const float *xa, float (&acc)[CC], const int *__restrict__ pos)
     {
         for (int e = e0; e < e0 + n; ++e) {
             const float vv = val[e];
-            const float *x = xa + (col[e] - gs) * CP;
+            const float *x = xa + (pos ? pos[col[e]] : col[e] - gs) * CP;
 #pragma unroll
             for (int c = 0; c < CC; ++c) acc[c] = fmaf(vv, x[c], acc[c]);
         }
@@ -255,6 +257,7 @@ template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
     static constexpr int MINW = 4;                // <= 128 VGPRs (60 of them values): two 512-thread workgroups per CU
     static constexpr int AHEAD = 2;               // gathers in flight (one fewer than OpCsr: the ring costs 4 VGPRs a stage)
     static constexpr bool FRAMES = true;          // SellDev.frames != NULL: rotate in and out of the local frames in LDS
+    static constexpr bool POS = false;            // layout-0 packs (LDS rows = local rows)
     float v[DMAX][3];
     unsigned lc[DMAX / 2];
     __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)   // see OpBsr3::load
@@ -310,7 +313,7 @@ template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
     template <class Mid>
     __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[3], Mid mid) const { mid(); dispatch<2>((w + 1) >> 1, xa, acc); }
     static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
-                                                int gs, const float *xa, float (&acc)[3])
+                                                int gs, const float *xa, float (&acc)[3], const int *__restrict__)
     {
         for (int e = e0; e < e0 + n; ++e) {
             if constexpr (SIGNED) {          // global arrays in the packed form of k_csr_step<.., 4>
@@ -375,6 +378,43 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab,
             xa[r * CP + c] = y;
             xa[(R + sell_copyB(r, R)) * CP + c] = y;
         }
+        p = p0;
+    }
+    __syncthreads();
+    return p;
+}
+
+// the same for layout-1 packs: every owner builds its own row of the first vector (at its position xr, copy B at rB) from
+// the staged input, which is in the operator's row order (row r)
+template <bool BWD, int NT>
+__device__ __forceinline__ int chain_prologue_pos(float *xa, float *xb, float *slab, const float *inb, int rows, bool own, int r,
+                                                  int xr, int rB, int C, int CP, int F, int T, const EvTable &tab, int Fs, int so)
+{
+    const int tid = threadIdx.x;
+    int p;
+    if (tid < CP) { xa[rows * CP + tid] = 0.f; xb[rows * CP + tid] = 0.f; }
+    if (!BWD) {
+        int p1 = 0; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
+        if (own)
+            for (int c = 0; c < C; ++c) {
+                const int i = r * C + c; const float y = inb[i];
+                xa[xr * CP + c] = y;
+                xa[rB * CP + c] = y;
+                if (so) slab[i * Fs] = y;
+                for (int k = 0; k < p1; ++k)
+                    if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * Fs + so, y, tab.e[k].slot, tab.e[k].sign);
+            }
+        p = p1;
+    } else {
+        int p0 = tab.n; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
+        if (own)
+            for (int c = 0; c < C; ++c) {
+                const int i = r * C + c; float y = 0.f;
+                for (int k = p0; k < tab.n; ++k)
+                    if (tab.e[k].chan < 0 || tab.e[k].chan == c) y += (tab.e[k].sign & 2) ? -slab[i * F + tab.e[k].slot] : slab[i * F + tab.e[k].slot];
+                xa[xr * CP + c] = y;
+                xa[rB * CP + c] = y;
+            }
         p = p0;
     }
     __syncthreads();
@@ -467,6 +507,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
              float *__restrict__ RES, int T, EvTable tab, int F, int n_parts, int max_rows, int early)
 {
     constexpr int C = Op::C, CP = Op::CP;
+    constexpr bool POS = Op::POS;
     extern __shared__ __align__(16) float smem[];
     const int nv = 2 * sell_padR(max_rows) * CP;                 // two copies per vector, a multiple of 32 floats
     const int so = ORD ? 1 : 0, Fs = F + so;                    // fused orders: slab rows are [x | bank]
@@ -514,7 +555,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 __syncthreads();
             }
             if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
-            else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+            else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
         }
         STAMP(li, 2);
 
@@ -522,7 +563,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         const int r = (rt & 0x3ff) == 0x3ff ? -1 : (rt & 0x3ff);
         const int tn = (int)((unsigned)rt >> 10);
         const bool own = r >= 0;
-        const int rB = own ? R + sell_copyB(r, R) : 0;
+        const int xr = POS ? (int)threadIdx.x : r;                       // LDS row this thread writes: its position / its row
+        const int rB = own ? R + (POS ? sell_swzB(xr) : sell_copyB(r, R)) : 0;
         // input staged?  (first part, or the late copy of the single-slab backward: wait for it -- and, loads being
         // returned in order, for the operator issued after it; otherwise it landed many steps ago)
         if (prev_rows < 0 || (BWD && !early)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -533,7 +575,10 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
             else rotate_rows<true, NT>(slab, sd.frames + (int64_t)gs * 9, rows, F, 3 * F, F);
             __syncthreads();
         }
-        int p = chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab, Fs, so);
+        int p = POS ? chain_prologue_pos<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, own, r, xr, rB, C, CP, F, T, tab, Fs, so)
+                    : chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab, Fs, so);
+        if (POS && BWD && T == 0 && own)          // no step: the Horner start is the answer
+            for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = xa[xr * CP + c];
         STAMP(li, 4);
 
         int rtN = 0, te0N = 0, swN = 0;
@@ -556,7 +601,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
             // nothing from this step: it runs while the first gathers are in flight instead of ahead of the barrier.
             op.gather(xa, w, acc, [&]() {
                 if (!BWD && own && pq1 > pq0) {
-                    XVec<CP> yp; yp.load(xa + r * CP);
+                    XVec<CP> yp; yp.load(xa + xr * CP);
 #pragma unroll
                     for (int c = 0; c < C; ++c) apply_events<false>(tab, pq0, pq1, c, yp.v[c], slab + (r * C + c) * Fs + so);
                 }
@@ -565,7 +610,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
             if (t == 5) { STAMPW(li, 9, 0); STAMPW(li, 13, NT - 64); }
 #endif
             if (own) {
-                if (tn) Op::tail(val, col, te0, tn, gs, xa, acc);
+                if (tn) Op::tail(val, col, te0, tn, gs, xa, acc, POS ? sd.pos_of_row : nullptr);
                 XVec<CP> y;
 #pragma unroll
                 for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
@@ -576,7 +621,11 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
 #pragma unroll
                     for (int c = 0; c < C; ++c) y.v[c] = acc[c];
                 }
-                y.store(xb + r * CP); y.store(xb + rB * CP);       // whole padded rows: one wide store per copy
+                y.store(xb + xr * CP); y.store(xb + rB * CP);      // whole padded rows: one wide store per copy
+                if (POS && BWD && t == T) {       // layout 1: the owner holds the answer of its row -- straight to HBM
+#pragma unroll
+                    for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = y.v[c];
+                }
                 if (!BWD && t == T) {             // the last step has no successor to hide behind
 #pragma unroll
                     for (int c = 0; c < C; ++c) apply_events<false>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
@@ -618,7 +667,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         __syncthreads();
     }
     if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
-    else chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+    else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
 }
 
 template <class Op, int NT, bool BWD, bool ORD>
@@ -660,6 +709,9 @@ static int launch_sell_k(const int *ci, const float *v, int n_parts, int max_row
                          float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
     if (sd.nsl * 64 != NT) return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d does not match parts of <= %d rows", sd.nsl, max_rows);
+    if (sd.layout != (Op::POS ? 1 : 0))
+        return fail(ESCAT_EINVAL, "escat_sell.layout=%d: this operator family takes layout %d packs", sd.layout, Op::POS ? 1 : 0);
+    if (Op::POS && !sd.pos_of_row) return fail(ESCAT_EINVAL, "escat_sell.pos_of_row is NULL (layout 1)");
     if (!BWD && sd.orders) return launch_sell_k2<Op, NT, false, true>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
     return launch_sell_k2<Op, NT, BWD, false>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
 }

@@ -110,7 +110,7 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
             pl, pr, nl = plist.data_ptr(), prow0.data_ptr(), int(plist.numel())
         sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(),
                                      sell.dmax, sell.n_slices, sell.slices_per_part, sell.val_planes, 0, 0, 0, pl, pr, nl, orders,
-                                     frames.data_ptr() if frames is not None else 0)
+                                     frames.data_ptr() if frames is not None else 0, sell.layout, sell.pos_of_row.data_ptr())
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on
@@ -118,11 +118,11 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         # random node order where the x gather dominates), so the default multi-launch path stays unpacked.
         sg = form.sell_global()
         sell_struct = _lib.EscatSell(sg.val.data_ptr(), 0, 0, 0, sg.n_slices, 0, 0,
-                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0, 0, 0)
+                                     sg.col32.data_ptr(), sg.perm.data_ptr(), sg.slice_doff.data_ptr(), 0, 0, 0, 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif per_channel_vals:
         # no pack (graphs too large for the register path): a descriptor that only says how val / col are laid out
-        sell_struct = _lib.EscatSell(0, 0, 0, 0, 0, 0, 4 if form.signed_pack() is not None else 3, 0, 0, 0, 0, 0, 0, 0, 0)
+        sell_struct = _lib.EscatSell(0, 0, 0, 0, 0, 0, 4 if form.signed_pack() is not None else 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     col_t, val_t = form.col, form.val
     if per_channel_vals and (sell.val_planes == 4 if sell is not None else form.signed_pack() is not None):

@@ -128,7 +128,51 @@ typedef struct {
      * D Pt^t D^T (the vector operator in factored form, D = blockdiag(O)): inputs are rotated into the frames and results
      * back out inside the kernel, in LDS.  NULL: the chain on Pt itself. */
     const float    *frames;
+    /* how LDS rows are numbered (ABI version 2).  0: an LDS row is the part's local row index, copy B rotates bits 0-3 of
+     * it to the top of its 256-row block (the description above; per-channel packs, val_planes = 3 / 4, use it).
+     * 1: an LDS row is a POSITION = the lane index, inside the part, of the thread that serves the row (rows sorted by
+     * length), copy B = R + ((p & ~15) | ((p + 1 + (p >> 5) % 15) & 15)): the owner stores its new vector row at its own
+     * thread index, so both copies' 16-byte stores are bank-conflict-free.  Scalar (val_planes 0/1) and BSR-3 packs
+     * must be layout 1 and bring pos_of_row[global row] = position (the streamed tails of rows longer than dmax need
+     * it).  escat_sell_pack_plan / _fill build either layout. */
+    int32_t         layout;
+    const int32_t  *pos_of_row;
 } escat_sell;
+
+/* ---- the pack itself, built on the GPU (replaces round 1's torch index ops; esc_gnn_amd/operators.py::Sell calls
+ * these).  Two phases because the pack's size depends on the data:
+ *   escat_sell_pack_plan   picks dmax from the row-length histogram, orders every part's rows by length (stable,
+ *                          descending), sizes the slices and prefix-sums their offsets into `workspace`; reads two
+ *                          small results back (it synchronises `stream`) and fills *dims (host);
+ *   escat_sell_pack_fill   with val_out (dims->val_floats floats, 16-byte aligned), lc_out (dims->lc_words words) and
+ *                          lane_meta_out (n_slices*64*3 ints) allocated by the caller: one wave per slice plans slots and
+ *                          vector copies (as escat_sell_plan_slots) and writes the slice.  The same workspace must be
+ *                          passed to both; afterwards it holds (int32) hist[64] | w[ns] | doff[ns+1] | poff[ns+1] |
+ *                          perm[ns*64] | pos_of_row[n] with ns = n_slices, of which pos_of_row is what escat_sell wants.
+ * values_per_entry: 1 (CSR), 9 (BSR-3 blocks, row-major), 3 (one value per channel); with sign_bits != NULL
+ * (values_per_entry 3) `val` is (nnz,) magnitudes and sign_bits[e] bits 0..2 the channels' signs: the val_planes = 4
+ * format.  slot_of_e / lc_of_e (nnz ints each, optional, both or neither): the plan per entry, for diagnostics. */
+typedef struct {
+    int32_t dmax, n_slices, slices_per_part, layout;
+    int64_t total_d, total_p;           /* slots / LDS-row pairs over all slices */
+    int64_t val_floats, lc_words;       /* elements of val / lc to allocate (padding slot / pair included) */
+} escat_sell_dims;
+size_t escat_sell_pack_workspace_bytes(int64_t n, int n_parts);
+int escat_sell_pack_plan(const int32_t *rowptr, int64_t n, const int32_t *part_ptr, int n_parts, int max_part_rows,
+                         int values_per_entry, int layout, void *workspace, size_t workspace_bytes,
+                         escat_sell_dims *dims, void *stream);
+int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *sign_bits,
+                         int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
+                         const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
+                         float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
+                         int32_t *slot_of_e, int32_t *lc_of_e, void *stream);
+
+/* The transposed operator for the backward entry points when the PATTERN is symmetric (undirected graphs: P and Q of
+ * process_pyg_data always are): A^T then lives on A's own rowptr / col, and val_t[(j,i)] = val[(i,j)] (3x3 blocks
+ * transposed for values_per_entry = 9).  *not_symmetric (device, caller zeroes) is set to 1 if some (i,j) has no (j,i):
+ * val_t is then incomplete and the caller must transpose the general way. */
+int escat_transpose_sym(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
+                        int values_per_entry, float *val_t, int32_t *not_symmetric, void *stream);
 
 /* Pack-time planning for escat_sell: for every entry e among the first dmax of its row, the slot (column of its
  * slice) and the LDS row (vector copy A or B) it will use, chosen so that the 16 lanes of each ds_read_b128 lane

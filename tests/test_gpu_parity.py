@@ -45,7 +45,7 @@ def _ops(sg, dev):
 def test_library_loaded_and_native():
     from esc_gnn_amd import _lib
     lib = _lib.load()
-    assert lib.escat_abi_version() == 1
+    assert lib.escat_abi_version() == 2
 
 
 @pytest.mark.parametrize("mode", list(MODES))
@@ -275,19 +275,21 @@ def _gather_cycles(lds_rows):
 
 
 def test_sell_slot_plan_is_a_valid_permutation_and_cuts_conflicts():
-    """escat_sell_plan_slots: every kept entry gets a distinct slot of its row, its LDS row is the local column in
-    copy A or copy B, and the planned gathers hit fewer equal bank slots than the natural order."""
+    """the pack's slot plan (escat_sell_pack_fill): every kept entry gets a distinct slot of its row, its LDS row is the
+    POSITION of its column's owner in copy A or copy B (layout 1), and the planned gathers hit fewer equal bank slots
+    than the natural order."""
     from esc_gnn_amd import ScatterOperator, synthetic
-    from esc_gnn_amd.operators import sell_pad_rows, sell_copy_b
+    from esc_gnn_amd.operators import sell_pad_rows, sell_swz_b
     dev = _dev()
     b = synthetic.ellipsoid_batch(3, 500, 10, seed=21)
     t = lambda a: torch.from_numpy(a).to(dev)
     form = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"]).bsr3()
-    sell = form.sell()
+    sell = form.sell(keep_plan=True)
+    assert sell.layout == 1
     slot = sell.slot_of_e.cpu().numpy()[:form.nnz]; lrow = sell.lc_of_e.cpu().numpy()[:form.nnz]
+    pos = sell.pos_of_row.cpu().numpy().astype(np.int64)
     rp, col, pp = b["rowptr"].astype(np.int64), b["col"].astype(np.int64), form.part_ptr.cpu().numpy().astype(np.int64)
     part_of_row = np.repeat(np.arange(form.n_parts), np.diff(pp))
-    planned_cols, natural_cols = [], []
     for r in range(form.n):
         e0, e1 = rp[r], rp[r + 1]
         kept = min(e1 - e0, sell.dmax)
@@ -296,8 +298,15 @@ def test_sell_slot_plan_is_a_valid_permutation_and_cuts_conflicts():
         gs = pp[part_of_row[r]]; R = sell_pad_rows(int(pp[part_of_row[r] + 1] - gs))
         for e in range(e0, e1):
             if slot[e] >= 0:
-                a = int(col[e] - gs)
-                assert lrow[e] in (a, R + sell_copy_b(a, R)), (r, e, a, lrow[e])
+                a = int(pos[col[e]])
+                assert lrow[e] in (a, R + sell_swz_b(a)), (r, e, a, lrow[e])
+    # positions: a permutation of 0..rows-1 inside every part, rows sorted by length (descending, stable)
+    for g in range(form.n_parts):
+        pr = pos[pp[g]:pp[g + 1]]
+        assert sorted(pr.tolist()) == list(range(len(pr)))
+        deg = np.minimum(np.diff(rp)[pp[g]:pp[g + 1]], sell.dmax)
+        order = np.argsort(pr)
+        assert (np.diff(deg[order]) <= 0).all()
     # conflict statistic of the first slice of the first part: planned vs natural order
     perm = sell.perm.cpu().numpy()[:64]
     rows0 = int(pp[1] - pp[0]); w = int(sell.slice_doff[1] - sell.slice_doff[0])
@@ -306,10 +315,74 @@ def test_sell_slot_plan_is_a_valid_permutation_and_cuts_conflicts():
         if r < 0:
             continue
         for d, e in enumerate(range(rp[r], min(rp[r + 1], rp[r] + sell.dmax))):
-            nat_tab[d, lane] = col[e]
+            nat_tab[d, lane] = pos[col[e]]
             plan_tab[slot[e], lane] = lrow[e]
     c_nat, c_plan = _gather_cycles(nat_tab), _gather_cycles(plan_tab)
     assert c_plan < 0.8 * c_nat, (c_plan, c_nat)
+    # stores: the 8 consecutive lanes of a ds_write_b128 lane group hit 8 distinct 16-byte slots (mod 8) in both copies
+    p = np.arange(512)
+    for grp in p.reshape(-1, 8):
+        assert len(set((grp % 8).tolist())) == 8 and len(set((sell_swz_b(grp) % 8).tolist())) == 8
+    assert ((sell_swz_b(p) & 15) != (p & 15)).all() and sorted(sell_swz_b(p).tolist()) == p.tolist()
+
+
+def test_gpu_pack_layout0_is_bit_identical_to_the_round1_torch_pack():
+    """escat_sell_pack_plan / _fill (HIP) against round 1's torch-op pack (tests/torch_sell_reference.py) in the layout
+    both know (0): val, lc, lane_meta, perm and the slice offsets bit for bit -- scalar CSR, BSR-3, per-channel CSR
+    (three planes) and the sign-bit form; ragged parts, rows longer than dmax."""
+    from esc_gnn_amd import ScatterOperator, synthetic
+    from esc_gnn_amd.operators import Sell
+    from tests.torch_sell_reference import TorchSell
+    dev = _dev()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    b = _concat_batches([synthetic.ellipsoid_batch(3, 180, 9, seed=1), synthetic.ellipsoid_batch(2, 90, 30, seed=2),
+                         synthetic.ellipsoid_batch(5, 33, 4, seed=3), synthetic.ellipsoid_batch(2, 400, 10, seed=4)])
+    rowptr, col = t(b["rowptr"]), t(b["col"])
+    g = torch.Generator().manual_seed(0)
+    v3 = torch.randn(b["nnz"], 3, generator=g).to(dev)
+    sg = t(b["pval"])[:, None] * torch.where(torch.rand(b["nnz"], 3, generator=g).to(dev) < 0.5, -1.0, 1.0)
+    forms = [ScatterOperator.from_csr(rowptr, col, t(b["pval"]), b["N"]).csr(),
+             ScatterOperator.from_bsr3(rowptr, col, t(b["blk"]), b["N"]).bsr3(),
+             ScatterOperator.from_csr(rowptr, col, v3, b["N"], validate=False).csr(),
+             ScatterOperator.from_csr(rowptr, col, sg.contiguous(), b["N"], validate=False).csr()]
+    for k, form in enumerate(forms):
+        ref = TorchSell(form)
+        got = Sell(form, keep_plan=True, layout=0)
+        assert got.dmax == ref.dmax and got.n_slices == ref.n_slices and got.slices_per_part == ref.slices_per_part
+        assert got.val_planes == ref.val_planes
+        assert torch.equal(got.perm, ref.perm), k
+        assert torch.equal(got.slice_doff.long(), ref.slice_doff.long()) and torch.equal(got.slice_poff.long(), ref.slice_poff.long())
+        assert torch.equal(got.slot_of_e[:form.nnz], ref.slot_of_e[:form.nnz]) and torch.equal(got.lc_of_e[:form.nnz], ref.lc_of_e[:form.nnz])
+        assert torch.equal(got.val, ref.val), k
+        assert torch.equal(got.lc, ref.lc), k
+        assert torch.equal(got.lane_meta, ref.lane_meta), k
+
+
+def test_transpose_on_symmetric_pattern_matches_the_sorted_transpose():
+    """escat_transpose_sym (values moved on A's own pattern) = the sort-based transpose, bit for bit, for CSR and BSR-3;
+    a non-symmetric pattern is detected and takes the general path."""
+    from esc_gnn_amd import ScatterOperator, synthetic
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(7, 120, 6, seed=12)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for op, form_of, tr in ((ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"]), "csr", "csr_t"),
+                            (ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"]), "bsr3", "bsr3_t")):
+        f, ft = getattr(op, form_of)(), getattr(op, tr)()
+        assert ft.rowptr.data_ptr() == f.rowptr.data_ptr()                  # shares the pattern
+        n = f.n
+        rp = f.rowptr.long()
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+        order = torch.argsort(f.col.long() * n + rows)
+        want = f.val[order] if f.val.dim() == 1 else f.val[order].transpose(1, 2)
+        assert torch.equal(ft.val, want.contiguous())
+        assert torch.equal(ft.col.long(), rows[order])
+    # upper-triangular operator: not symmetric -> general path, still correct
+    rowptr = torch.tensor([0, 2, 3, 4], dtype=torch.int32, device=dev)
+    col = torch.tensor([0, 2, 1, 2], dtype=torch.int32, device=dev)
+    val = torch.tensor([1., 2., 3., 4.], device=dev)
+    opU = ScatterOperator.from_csr(rowptr, col, val, 3)
+    ct = opU.csr_t()
+    assert ct.rowptr.tolist() == [0, 1, 2, 4] and ct.col.tolist() == [0, 1, 0, 2] and ct.val.tolist() == [1., 3., 2., 4.]
 
 
 def _concat_batches(bs):
