@@ -82,6 +82,49 @@ k_pack_scan(const int *__restrict__ w, int n_slices, int *__restrict__ doff, int
     if (t == 1023) { doff[n_slices] = (int)sd[1023]; poff[n_slices] = (int)sp[1023]; }
 }
 
+// one entry's values into slot `slot` (absolute) of the packed array, lane `lane`; e < 0: a padded slot (zeros)
+template <int V, bool SIGNED>
+__device__ __forceinline__ void put_values(float *__restrict__ val_out, int64_t slot, int lane, const float *__restrict__ val, int64_t e)
+{
+    constexpr int PER = V == 9 ? 576 : (V == 3 && !SIGNED ? 192 : 64);
+    float *o = val_out + slot * PER;
+    if constexpr (V == 9) {
+        float b[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) b[q] = e >= 0 ? val[e * 9 + q] : 0.f;
+        // pieces b00 b10 b01 b11 | b02 b12 b20 b21 | b22   (bij = row i, column j: b[3*i + j])
+        *reinterpret_cast<float4 *>(o + lane * 4) = make_float4(b[0], b[3], b[1], b[4]);
+        *reinterpret_cast<float4 *>(o + 256 + lane * 4) = make_float4(b[2], b[5], b[6], b[7]);
+        o[512 + lane] = b[8];
+    } else if constexpr (V == 3 && !SIGNED) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c * 64 + lane] = e >= 0 ? val[e * 3 + c] : 0.f;
+    } else {
+        o[lane] = e >= 0 ? val[e] : 0.f;
+    }
+}
+
+// values only, for an operator that shares pattern, capacity and layout with one already packed (its transpose on a
+// symmetric pattern; P and Q of one batch): the plan (ent_of_slot: which entry of the row sits in each slot) is reused,
+// lc / lane_meta / pos_of_row are shared.
+template <int V>
+__global__ void __launch_bounds__(256)
+k_pack_refill(const int *__restrict__ rowptr, const float *__restrict__ val, const int *__restrict__ part_ptr,
+              const int *__restrict__ perm, const int *__restrict__ doff_, const signed char *__restrict__ ent, int nsl,
+              int n_slices, float *__restrict__ val_out)
+{
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n_slices) return;
+    const int gs = part_ptr[s / nsl];
+    const int r = perm[(int64_t)s * 64 + lane];
+    const int doff = doff_[s], w = doff_[s + 1] - doff;
+    const int64_t e0 = r >= 0 ? rowptr[gs + r] : 0;
+    for (int k = 0; k < w; ++k) {
+        const int j = ent[(int64_t)(doff + k) * 64 + lane];
+        put_values<V, false>(val_out, doff + k, lane, val, j >= 0 ? e0 + j : -1);
+    }
+}
+
 // ------------------------------------------------------------------ plan + fill, one wave per slice
 // V: floats per entry in `val` (1 scalar, 3 one per channel, 9 a 3x3 block); SIGNED (V == 3 input given as |value| +
 // sign bits): one plane of magnitudes, the three signs in bits 11..13 of the entry's 16-bit LDS-row field.
@@ -91,7 +134,7 @@ k_pack_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const f
             const int *__restrict__ sign_bits, const int *__restrict__ part_ptr, const int *__restrict__ perm,
             const int *__restrict__ pos_of_row, const int *__restrict__ doff_, const int *__restrict__ poff_,
             int dmax, int nsl, float *__restrict__ val_out, unsigned *__restrict__ lc_out, int *__restrict__ lane_meta,
-            int *__restrict__ slot_of_e, int *__restrict__ lc_of_e)
+            int *__restrict__ slot_of_e, int *__restrict__ lc_of_e, signed char *__restrict__ ent_out)
 {
     __shared__ short cols[64][33];                 // LDS row candidates (copy A) of each lane's kept entries
     __shared__ signed char ent_of_slot[64][32];    // after planning: which entry sits in slot k (-1: none)
@@ -151,24 +194,10 @@ k_pack_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const f
         }
     }
     // ---- values: slot-major, every store of the wave one contiguous run
-    constexpr int PER = V == 9 ? 576 : (V == 3 && !SIGNED ? 192 : 64);
     for (int k = 0; k < w; ++k) {
         const int j = ent_of_slot[lane][k];
-        float *o = val_out + (int64_t)(doff + k) * PER;
-        if constexpr (V == 9) {
-            float b[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) b[q] = j >= 0 ? val[(int64_t)(e0 + j) * 9 + q] : 0.f;
-            // pieces b00 b10 b01 b11 | b02 b12 b20 b21 | b22   (bij = row i, column j: b[3*i + j])
-            *reinterpret_cast<float4 *>(o + lane * 4) = make_float4(b[0], b[3], b[1], b[4]);
-            *reinterpret_cast<float4 *>(o + 256 + lane * 4) = make_float4(b[2], b[5], b[6], b[7]);
-            o[512 + lane] = b[8];
-        } else if constexpr (V == 3 && !SIGNED) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[c * 64 + lane] = j >= 0 ? val[(int64_t)(e0 + j) * 3 + c] : 0.f;
-        } else {
-            o[lane] = j >= 0 ? val[e0 + j] : 0.f;
-        }
+        put_values<V, SIGNED>(val_out, doff + k, lane, val, j >= 0 ? e0 + j : -1);
+        if (ent_out) ent_out[(int64_t)(doff + k) * 64 + lane] = (signed char)j;
     }
     // ---- packed LDS rows: pairs cover w rounded up to 4 slots; slots past the row's end read the zero row
     const int npair = ((w + 3) / 4) * 2;
@@ -277,7 +306,7 @@ extern "C" int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, c
                                     int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
                                     const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
                                     float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
-                                    int32_t *slot_of_e, int32_t *lc_of_e, void *stream)
+                                    int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream)
 {
     if (!rowptr || !col || !val || !part_ptr || !dims || !workspace || !val_out || !lc_out || !lane_meta_out)
         return fail(ESCAT_EINVAL, "NULL pointer");
@@ -296,7 +325,8 @@ extern "C" int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, c
     if (e == hipSuccess && slot_of_e) e = hipMemsetAsync(slot_of_e, 0xff, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t), st);
     if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
 #define GO(VV, SG, LY) hipLaunchKernelGGL((k_pack_fill<VV, SG, LY>), dim3((unsigned)ns), dim3(64), 0, st, rowptr, col, val, sign_bits, \
-        part_ptr, ws.perm, ws.pos, ws.doff, ws.poff, dims->dmax, dims->slices_per_part, val_out, lc_out, lane_meta_out, slot_of_e, lc_of_e)
+        part_ptr, ws.perm, ws.pos, ws.doff, ws.poff, dims->dmax, dims->slices_per_part, val_out, lc_out, lane_meta_out, slot_of_e, lc_of_e, \
+        (signed char *)ent_of_slot)
     const int ly = dims->layout;
     if (values_per_entry == 9) { if (ly) GO(9, false, 1); else GO(9, false, 0); }
     else if (values_per_entry == 1) { if (ly) GO(1, false, 1); else GO(1, false, 0); }
@@ -304,6 +334,30 @@ extern "C" int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, c
     else { if (ly) GO(3, false, 1); else GO(3, false, 0); }
 #undef GO
     CHECK_LAUNCH("escat_sell_pack_fill");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_sell_pack_refill(const int32_t *rowptr, const float *val, int64_t n, const int32_t *part_ptr, int n_parts,
+                                      int values_per_entry, const escat_sell_dims *dims, const void *workspace,
+                                      size_t workspace_bytes, const int8_t *ent_of_slot, float *val_out, void *stream)
+{
+    if (!rowptr || !val || !part_ptr || !dims || !workspace || !ent_of_slot || !val_out) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (((uintptr_t)val_out & 15) != 0) return fail(ESCAT_EINVAL, "val_out must be 16-byte aligned");
+    const int64_t ns = dims->n_slices;
+    if (ns != (int64_t)n_parts * dims->slices_per_part) return fail(ESCAT_EINVAL, "dims do not belong to this operator");
+    if (workspace_bytes < pack_ws_ints(n, (int64_t)n_parts * 8) * sizeof(int)) return fail(ESCAT_EWORKSPACE, "workspace too small");
+    PackWs ws = pack_ws(const_cast<void *>(workspace), n, ns);
+    hipStream_t st = S(stream);
+    const int per = values_per_entry == 9 ? 576 : values_per_entry == 3 ? 192 : 64;
+    hipError_t e = hipMemsetAsync(val_out + dims->total_d * per, 0, (size_t)per * sizeof(float), st);
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    const unsigned grid = (unsigned)((ns + 3) / 4);
+#define GO(VV) hipLaunchKernelGGL((k_pack_refill<VV>), dim3(grid), dim3(256), 0, st, rowptr, val, part_ptr, ws.perm, ws.doff, \
+                                  (const signed char *)ent_of_slot, dims->slices_per_part, (int)ns, val_out)
+    if (values_per_entry == 9) GO(9); else if (values_per_entry == 3) GO(3); else if (values_per_entry == 1) GO(1);
+    else return fail(ESCAT_EINVAL, "values_per_entry=%d: 1, 3 or 9", values_per_entry);
+#undef GO
+    CHECK_LAUNCH("escat_sell_pack_refill");
     return ESCAT_OK;
 }
 
@@ -348,4 +402,48 @@ extern "C" int escat_transpose_sym(const int32_t *rowptr, const int32_t *col, co
     else return fail(ESCAT_EINVAL, "values_per_entry=%d: 1, 3 or 9", values_per_entry);
     CHECK_LAUNCH("escat_transpose_sym");
     return ESCAT_OK;
+}
+
+// ------------------------------------------------------------------ diagonal blocks of a block-diagonal operator
+// A cut between rows c and c+1 is legal iff no row "straddles" it, i.e. no row r has both c and c+1 inside
+// [min(r, first column), max(r, last column)].  Every row adds +1 at its interval's start and -1 at its end; after a
+// prefix sum (the caller's) the legal cuts are the zeros.  Rows are sorted by column (canonical CSR).
+__global__ void __launch_bounds__(256)
+k_row_cover(const int *__restrict__ rowptr, const int *__restrict__ col, int64_t n, int *__restrict__ delta)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    int lo = (int)r, hi = (int)r;
+    if (e1 > e0) { const int a = col[e0], b = col[e1 - 1]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (hi > lo) { atomicAdd(&delta[lo], 1); atomicAdd(&delta[hi], -1); }
+}
+
+extern "C" int escat_row_cover(const int32_t *rowptr, const int32_t *col, int64_t n, int32_t *delta, void *stream)
+{
+    if (!rowptr || !delta) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n <= 0) return ESCAT_OK;
+    hipLaunchKernelGGL(k_row_cover, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), rowptr, col, n, delta);
+    CHECK_LAUNCH("escat_row_cover");
+    return ESCAT_OK;
+}
+
+// host utility: greedy merge of consecutive diagonal blocks (bounds[0] = 0 < ... < bounds[nb-1] = n, HOST pointers) into
+// parts of at most `target` rows (a block larger than the target stays alone); returns the number of part boundaries
+// written to out (out[0] = 0, last = n), or a negative error code.
+extern "C" int64_t escat_merge_row_ranges(const int64_t *bounds, int64_t nb, int64_t target, int32_t *out, int32_t *max_rows)
+{
+    if (!bounds || !out || !max_rows || nb < 2) return fail(ESCAT_EINVAL, "bad bounds");
+    int64_t k = 0, start = bounds[0], mx = 0;
+    out[k++] = (int32_t)start;
+    for (int64_t i = 1; i < nb; ++i)
+        if (bounds[i] - start > target && bounds[i - 1] > start) {
+            if (bounds[i - 1] - start > mx) mx = bounds[i - 1] - start;
+            start = bounds[i - 1];
+            out[k++] = (int32_t)start;
+        }
+    if (bounds[nb - 1] - start > mx) mx = bounds[nb - 1] - start;
+    out[k++] = (int32_t)bounds[nb - 1];
+    *max_rows = (int32_t)mx;
+    return k;
 }

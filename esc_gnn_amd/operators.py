@@ -31,16 +31,46 @@ def _rowptr(rows: torch.Tensor, n: int) -> torch.Tensor:
     return rp.to(torch.int32)
 
 
+_PARTS_CACHE = {}        # one entry: operators that share a pattern (P and Q of a batch) find their parts once
+
+
 def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: int):
     """
     Boundaries of the finest partition of rows 0..n into consecutive ranges that
     no entry leaves (cut after row r iff every row <= r has cols <= r and every
     row > r has cols > r), then greedily merged up to `target` rows.
     Returns (part_ptr int32 device tensor, n_parts, max_part_rows).
+    On the GPU: one kernel marks every row's column span (escat_row_cover), a prefix sum finds the cuts no span crosses,
+    the greedy merge of the (few thousand) blocks is a C loop on the host (escat_merge_row_ranges).
     """
     dev = rowptr.device
     if n == 0:
         return torch.zeros(1, dtype=torch.int32, device=dev), 0, 0
+    key = (rowptr.data_ptr(), col.data_ptr(), rowptr._version, col._version, n, int(col.numel()), target)
+    hit = _PARTS_CACHE.get("last")
+    if hit is not None and hit[0] == key and hit[1] is rowptr and hit[2] is col:
+        return hit[3]
+    if rowptr.is_cuda and rowptr.dtype == torch.int32 and col.dtype == torch.int32:
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        delta = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.escat_row_cover(ctypes.c_void_p(rowptr.data_ptr()), ctypes.c_void_p(col.data_ptr() if col.numel() else 0),
+                                           n, ctypes.c_void_p(delta.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "escat_row_cover")
+        cover = torch.cumsum(delta[:n - 1], 0, dtype=torch.int32) if n > 1 else delta[:0]
+        cuts = (torch.nonzero(cover == 0).flatten() + 1).cpu().numpy()
+        bounds = np.ascontiguousarray(np.concatenate([[0], cuts, [n]]).astype(np.int64))
+        out = np.empty(bounds.shape[0], dtype=np.int32)
+        mx = ctypes.c_int32(0)
+        k = lib.escat_merge_row_ranges(bounds.ctypes.data_as(ctypes.c_void_p), bounds.shape[0], target,
+                                       out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(mx))
+        if k < 2:
+            _lib.check(int(k), "escat_merge_row_ranges")
+        res = (torch.from_numpy(out[:k].copy()).to(dev), int(k) - 1, int(mx.value))
+        _PARTS_CACHE["last"] = (key, rowptr, col, res)
+        return res
     rp = rowptr.long()
     ar = torch.arange(n, device=dev)
     if col.numel() == 0:
@@ -160,6 +190,9 @@ def sell_swz_b(p):
     return (p & ~15) | ((p + 1 + ((p >> 5) % 15)) & 15)
 
 
+_PLAN_CACHE = {}         # (pattern identity, parts, dmax, layout) -> the last pack built on it (see Sell)
+
+
 class Sell:
     """
     SELL-64 pack of a CSR (val (nnz,), or (nnz,3): one value per channel) or BSR-3 (val (nnz,3,3)) operator; layout in
@@ -167,6 +200,9 @@ class Sell:
     ordering, slice sizing, bank-conflict-aware slot planning and the coalesced fill are HIP kernels); this class only
     allocates the arrays.  Scalar and BSR-3 packs use layout 1 (LDS rows = owner positions: conflict-free vector
     stores), per-channel packs layout 0.
+    Operators that share the very same rowptr / col tensors, parts, capacity and layout -- an operator and its transpose
+    on a symmetric pattern, P and Q of one batch -- share ONE plan: the second pack only refills the values
+    (escat_sell_pack_refill) and aliases lc / lane_meta / pos_of_row of the first.
     """
 
     def __init__(self, form, keep_plan: bool = False, layout=None):
@@ -185,55 +221,93 @@ class Sell:
         n, nnz = form.n, form.nnz
         if form.max_part_rows >= 0x3ff:
             raise ValueError("escat: part too large for the SELL lane record")
+        if self.val_planes == 4 and 2 * sell_pad_rows(form.max_part_rows) >= (1 << 11):
+            raise ValueError("escat: LDS row index does not leave room for the sign bits")
         vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
-        ws = torch.empty(lib.escat_sell_pack_workspace_bytes(n, form.n_parts) // 4, dtype=torch.int32, device=dev)
-        dims = _lib.EscatSellDims()
+        per = 576 if V == 9 else (192 if (V == 3 and signed is None) else 64)         # floats per slot of a slice
+        key = (form.rowptr.data_ptr(), form.col.data_ptr(), form.rowptr._version, form.col._version,
+               form.part_ptr.data_ptr(), form.n_parts, form.max_part_rows, n, nnz, self.layout, str(dev))
+        shared = None
+        if signed is None and not keep_plan and layout is None:
+            for cap_key, cand in _PLAN_CACHE.items():
+                if cap_key[:-1] == key and cand._pattern[0] is form.rowptr and cand._pattern[1] is form.col \
+                        and cand.dmax == self._capacity_for(V, cand):
+                    shared = cand
+                    break
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.escat_sell_pack_plan(vp(form.rowptr), n, vp(form.part_ptr), form.n_parts, form.max_part_rows, V,
-                                                self.layout, vp(ws), ws.numel() * 4, ctypes.byref(dims), st),
-                       "escat_sell_pack_plan")
-            ns = dims.n_slices
-            per = 576 if V == 9 else (192 if (V == 3 and signed is None) else 64)     # floats per slot of a slice
-            self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
-            self.lc = torch.empty(dims.lc_words, dtype=torch.int32, device=dev)
-            self.lane_meta = torch.empty((ns * 64, 3), dtype=torch.int32, device=dev)
-            if keep_plan:                                    # per-entry plan, for tests / diagnostics (8 B per entry)
-                self.slot_of_e = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-                self.lc_of_e = torch.zeros(max(nnz, 1), dtype=torch.int32, device=dev)
-            if signed is not None:
-                src_val, bits = signed[1], signed[2].to(torch.int32).contiguous()
+            if shared is not None:
+                dims = shared._dims
+                self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
+                _lib.check(lib.escat_sell_pack_refill(vp(form.rowptr), vp(form.val), n, vp(form.part_ptr), form.n_parts, V,
+                                                      ctypes.byref(dims), vp(shared._ws), shared._ws.numel() * 4,
+                                                      vp(shared._ent), vp(self.val), st), "escat_sell_pack_refill")
+                self.lc, self.lane_meta, ws, self._ent = shared.lc, shared.lane_meta, shared._ws, shared._ent
             else:
-                src_val, bits = form.val, None
-            if self.val_planes == 4 and bool((form.max_part_rows + 1 + 15) // 16 * 16 * 2 >= (1 << 11)):
-                raise ValueError("escat: LDS row index does not leave room for the sign bits")
-            _lib.check(lib.escat_sell_pack_fill(vp(form.rowptr), vp(form.col), vp(src_val),
-                                                vp(bits) if bits is not None else ctypes.c_void_p(0), n, nnz,
-                                                vp(form.part_ptr), form.n_parts, V, ctypes.byref(dims), vp(ws), ws.numel() * 4,
-                                                vp(self.val), vp(self.lc), vp(self.lane_meta),
-                                                vp(self.slot_of_e) if keep_plan else ctypes.c_void_p(0),
-                                                vp(self.lc_of_e) if keep_plan else ctypes.c_void_p(0), st),
-                       "escat_sell_pack_fill")
+                ws = torch.empty(lib.escat_sell_pack_workspace_bytes(n, form.n_parts) // 4, dtype=torch.int32, device=dev)
+                dims = _lib.EscatSellDims()
+                _lib.check(lib.escat_sell_pack_plan(vp(form.rowptr), n, vp(form.part_ptr), form.n_parts, form.max_part_rows, V,
+                                                    self.layout, vp(ws), ws.numel() * 4, ctypes.byref(dims), st),
+                           "escat_sell_pack_plan")
+                ns = dims.n_slices
+                self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
+                self.lc = torch.empty(dims.lc_words, dtype=torch.int32, device=dev)
+                self.lane_meta = torch.empty((ns * 64, 3), dtype=torch.int32, device=dev)
+                self._ent = torch.empty(max(dims.total_d, 1) * 64, dtype=torch.int8, device=dev) if signed is None else None
+                if keep_plan:                                    # per-entry plan, for tests / diagnostics (8 B per entry)
+                    self.slot_of_e = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+                    self.lc_of_e = torch.zeros(max(nnz, 1), dtype=torch.int32, device=dev)
+                if signed is not None:
+                    src_val, bits = signed[1], signed[2].to(torch.int32).contiguous()
+                else:
+                    src_val, bits = form.val, None
+                null = ctypes.c_void_p(0)
+                _lib.check(lib.escat_sell_pack_fill(vp(form.rowptr), vp(form.col), vp(src_val),
+                                                    vp(bits) if bits is not None else null, n, nnz,
+                                                    vp(form.part_ptr), form.n_parts, V, ctypes.byref(dims), vp(ws), ws.numel() * 4,
+                                                    vp(self.val), vp(self.lc), vp(self.lane_meta),
+                                                    vp(self.slot_of_e) if keep_plan else null,
+                                                    vp(self.lc_of_e) if keep_plan else null,
+                                                    vp(self._ent) if self._ent is not None else null, st),
+                           "escat_sell_pack_fill")
+        self._dims = dims
         self.dmax = int(dims.dmax)
         self.slices_per_part = int(dims.slices_per_part)
-        self.n_slices = int(ns)
+        self.n_slices = ns = int(dims.n_slices)
         # views of the workspace the kernels left behind: hist[64] | w[ns] | doff[ns+1] | poff[ns+1] | perm[ns*64] | pos[n]
         o = 64
+        self._hist = ws[:34]
         self.slice_w = ws[o:o + ns]; o += ns
         self.slice_doff = ws[o:o + ns + 1]; o += ns + 1
         self.slice_poff = ws[o:o + ns + 1]; o += ns + 1
         self.perm = ws[o:o + ns * 64]; o += ns * 64
         self.pos_of_row = ws[o:o + n]
         self._ws = ws
+        self._pattern = (form.rowptr, form.col)          # keeps the key's tensors alive (identity is part of the key)
         self.total_d = int(dims.total_d)
-        self._kept = None
+        if shared is None and self._ent is not None and layout is None:
+            _PLAN_CACHE.clear()                          # one pattern at a time: batches come and go
+            _PLAN_CACHE[key + (self.dmax,)] = self
+
+    @staticmethod
+    def _capacity_for(V, cand) -> int:
+        """the capacity escat_sell_pack_plan would choose for V values per entry on cand's row-length histogram"""
+        if getattr(cand, "_hist_host", None) is None:
+            cand._hist_host = cand._hist.cpu().tolist()
+            cand._n_rows = int(cand.pos_of_row.numel())
+        caps = _SELL_DMAX[V]
+        allowed = int(_SELL_TAIL_ROWS * cand._n_rows)
+        for c in caps:
+            if sum(cand._hist_host[c + 1:34]) <= allowed:
+                return c
+        return caps[-1]
 
     @property
     def pad_ratio(self) -> float:
-        """slots stored / entries kept (diagnostic; costs a reduction + sync when asked for)"""
-        if self._kept is None:
-            self._kept = float((self.lane_meta[:, 0] != 0x3ff).sum())      # lanes with a row (placeholder denominator)
-        return float(self.total_d * 64) / max(self._kept, 1.0)
+        """slots stored / entries kept (diagnostic; reads the row-length histogram back)"""
+        h = self._hist.cpu().tolist()
+        kept = sum(min(d, self.dmax) * h[d] for d in range(34))
+        return float(self.total_d * 64) / max(float(kept), 1.0)
 
 
 class SellGlobal:

@@ -165,7 +165,22 @@ int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, const float 
                          int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
                          const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
                          float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
-                         int32_t *slot_of_e, int32_t *lc_of_e, void *stream);
+                         int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream);
+/* Values only, for an operator that shares pattern (rowptr / col), parts, dmax and layout with one packed before -- its
+ * transpose on a symmetric pattern, or P and Q of one batch: pass the first pack's workspace and its ent_of_slot
+ * (total_d * 64 bytes, optional output of escat_sell_pack_fill: which entry of its row each slot holds, -1 = padding);
+ * lc, lane_meta and pos_of_row of the first pack are then shared as they are.  Not for sign-bit packs. */
+int escat_sell_pack_refill(const int32_t *rowptr, const float *val, int64_t n, const int32_t *part_ptr, int n_parts,
+                           int values_per_entry, const escat_sell_dims *dims, const void *workspace,
+                           size_t workspace_bytes, const int8_t *ent_of_slot, float *val_out, void *stream);
+
+/* Finding the diagonal blocks of a block-diagonal operator (the graphs of a PyG batch,
+ * models/escgnn_data_classes.py:20-27).  escat_row_cover: delta (n + 1 ints, caller zeroes) receives +1 / -1 at the ends
+ * of every row's column span; after a prefix sum, a cut after row c is legal iff the sum at c is 0.
+ * escat_merge_row_ranges (HOST pointers, no GPU): greedy merge of consecutive blocks bounds[0..nb) into parts of at
+ * most `target` rows; returns the number of boundaries written to out, *max_rows = the largest part. */
+int escat_row_cover(const int32_t *rowptr, const int32_t *col, int64_t n, int32_t *delta, void *stream);
+int64_t escat_merge_row_ranges(const int64_t *bounds, int64_t nb, int64_t target, int32_t *out, int32_t *max_rows);
 
 /* The transposed operator for the backward entry points when the PATTERN is symmetric (undirected graphs: P and Q of
  * process_pyg_data always are): A^T then lives on A's own rowptr / col, and val_t[(j,i)] = val[(i,j)] (3x3 blocks

@@ -113,3 +113,56 @@ def test_fused_orders_with_rows_larger_than_the_lds_tile():
     ref = np.concatenate([x.numpy()[..., None], bank, bank[..., iu[0]] * bank[..., iu[1]]], axis=-1)
     assert W.shape == ref.shape
     assert np.abs(W.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_closed_row_ranges_gpu_kernel_matches_the_torch_scan():
+    """diagonal blocks of a block-diagonal operator: escat_row_cover + prefix sum + escat_merge_row_ranges (GPU path)
+    against the cummax / cummin formulation (the CPU path), ragged graphs, several merge targets, and a non-symmetric
+    pattern whose blocks are only visible from the columns of later rows."""
+    from esc_gnn_amd import synthetic
+    from esc_gnn_amd.operators import _closed_row_ranges, _PARTS_CACHE
+    from tests.test_gpu_parity import _concat_batches
+    dev = _dev()
+    b = _concat_batches([synthetic.ellipsoid_batch(5, 37, 4, seed=1), synthetic.ellipsoid_batch(3, 300, 8, seed=2),
+                         synthetic.ellipsoid_batch(9, 12, 3, seed=3)])
+    rp, col = torch.from_numpy(b["rowptr"]), torch.from_numpy(b["col"])
+    for target in (1, 64, 256, 100000):
+        _PARTS_CACHE.clear()
+        want = _closed_row_ranges(rp, col, b["N"], target)
+        got = _closed_row_ranges(rp.to(dev), col.to(dev), b["N"], target)
+        assert got[1:] == want[1:] and torch.equal(got[0].cpu(), want[0])
+    # rows 0..2 only reach each other through row 2's first column and row 0's last one; row 3 alone; rows 4..5 coupled
+    rowptr = torch.tensor([0, 2, 3, 5, 6, 8, 9], dtype=torch.int32)
+    colx = torch.tensor([0, 2, 1, 0, 2, 3, 4, 5, 5], dtype=torch.int32)
+    _PARTS_CACHE.clear()
+    want = _closed_row_ranges(rowptr, colx, 6, 1)
+    got = _closed_row_ranges(rowptr.to(dev), colx.to(dev), 6, 1)
+    assert want[0].tolist() == [0, 3, 4, 6] and got[0].cpu().tolist() == [0, 3, 4, 6] and got[1:] == want[1:]
+
+
+def test_shared_plan_refill_equals_a_fresh_pack():
+    """an operator and its transpose on a symmetric pattern (and P / Q of one batch) share one pack plan: the second
+    pack is a values-only refill (escat_sell_pack_refill) aliasing lc / lane_meta -- it must equal a pack built from
+    scratch, and chains on it must match the oracle (covered by the parity suite, which runs on shared plans)."""
+    from esc_gnn_amd import ScatterOperator, synthetic
+    from esc_gnn_amd.operators import Sell, _PLAN_CACHE
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(9, 260, 9, seed=5)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rowptr, col = t(b["rowptr"]), t(b["col"])
+    _PLAN_CACHE.clear()
+    opP = ScatterOperator.from_csr(rowptr, col, t(b["pval"]), b["N"])
+    opQ = ScatterOperator.from_bsr3(rowptr, col, t(b["blk"]), b["N"])
+    sP = opP.csr().sell()                                     # plans
+    sPt = opP.csr_t().sell()                                  # shares P's plan (same rowptr / col tensors)
+    assert sPt.lc.data_ptr() == sP.lc.data_ptr() and sPt.lane_meta.data_ptr() == sP.lane_meta.data_ptr()
+    sQ = opQ.bsr3().sell()                                    # same pattern and capacity -> shares too
+    sQt = opQ.bsr3_t().sell()
+    if sQ.dmax == sP.dmax:
+        assert sQ.lc.data_ptr() == sP.lc.data_ptr() and sQt.lc.data_ptr() == sP.lc.data_ptr()
+    for form, shared in ((opP.csr_t(), sPt), (opQ.bsr3(), sQ), (opQ.bsr3_t(), sQt)):
+        fresh = Sell(form, keep_plan=True)                    # keep_plan: never shared
+        assert fresh.lc.data_ptr() != shared.lc.data_ptr()
+        assert fresh.dmax == shared.dmax and torch.equal(fresh.val, shared.val)
+        assert torch.equal(fresh.lc, shared.lc) and torch.equal(fresh.lane_meta, shared.lane_meta)
+        assert torch.equal(fresh.pos_of_row, shared.pos_of_row)
