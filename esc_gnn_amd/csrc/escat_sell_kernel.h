@@ -59,7 +59,10 @@ template <int DMAX> struct OpBsr3 {
     static constexpr bool FRAMES = false;
     static constexpr bool POS = true;             // takes layout-1 packs (LDS rows = owner positions)
     static constexpr int C = 3, CP = 4, MINW = 1;
-    static constexpr int RING = 4;                // LDS gathers in flight per lane (4 VGPRs each)
+#ifndef ESCAT_Q_RING
+#define ESCAT_Q_RING 4
+#endif
+    static constexpr int RING = ESCAT_Q_RING;     // LDS gathers in flight per lane (4 VGPRs each)
     // a block's 9 floats as the three pieces they are loaded in, ordered for packed fp32 math:
     //   b0 = (b00, b10, b01, b11)   b1 = (b02, b12, b20, b21)   b2 = b22       (bij = row i, column j of the block)
     // so that (y0, y1) += (b0j, b1j) * xj is one v_pk_fma_f32 per column j (xj broadcast by op_sel) and
@@ -587,6 +590,10 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
             rtN = lm[0]; te0N = lm[1]; swN = lm[2];
         }
         bool staged = !(has_next && (!BWD || early));   // "nothing to stage early"
+#ifndef ESCAT_DEFER_EVENTS
+#define ESCAT_DEFER_EVENTS 1
+#endif
+        constexpr bool DEFER = ESCAT_DEFER_EVENTS != 0;
         int pq0 = 0, pq1 = 0;                     // forward: events of the previous step, applied under this step's first gathers
         for (int t = 1; t <= T; ++t) {
             int q0, q1;
@@ -626,12 +633,12 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
 #pragma unroll
                     for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = y.v[c];
                 }
-                if (!BWD && t == T) {             // the last step has no successor to hide behind
+                if (!BWD && (t == T || !DEFER)) { // the last step has no successor to hide behind
 #pragma unroll
                     for (int c = 0; c < C; ++c) apply_events<false>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
                 }
             }
-            pq0 = q0; pq1 = (!BWD && t < T) ? q1 : q0;
+            pq0 = q0; pq1 = (!BWD && DEFER && t < T) ? q1 : q0;
 #ifdef ESCAT_STAMPS
             if (t == 5) { STAMPW(li, 10, 0); STAMPW(li, 14, NT - 64); }
 #endif
