@@ -82,25 +82,54 @@ k_pack_scan(const int *__restrict__ w, int n_slices, int *__restrict__ doff, int
     if (t == 1023) { doff[n_slices] = (int)sd[1023]; poff[n_slices] = (int)sp[1023]; }
 }
 
-// one entry's values into slot `slot` (absolute) of the packed array, lane `lane`; e < 0: a padded slot (zeros)
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // a 16-byte load that is only dword-aligned
+
+// one entry's V values (e < 0: a padded slot, zeros)
+template <int V>
+__device__ __forceinline__ void get_values(float (&b)[V], const float *__restrict__ val, int64_t e)
+{
+    if (e < 0) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) b[q] = 0.f;
+    } else if constexpr (V == 9) {                 // 36 contiguous bytes, dword-aligned: two 16-byte loads and one dword
+        const f4u lo = *reinterpret_cast<const f4u *>(val + e * 9), hi = *reinterpret_cast<const f4u *>(val + e * 9 + 4);
+        b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = lo.w; b[4] = hi.x; b[5] = hi.y; b[6] = hi.z; b[7] = hi.w;
+        b[8] = val[e * 9 + 8];
+    } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) b[q] = val[e * V + q];
+    }
+}
+
+// ... into slot `slot` (absolute) of the packed array, lane `lane`.  SIGNED: b[0] is the magnitude (one plane)
 template <int V, bool SIGNED>
-__device__ __forceinline__ void put_values(float *__restrict__ val_out, int64_t slot, int lane, const float *__restrict__ val, int64_t e)
+__device__ __forceinline__ void store_values(float *__restrict__ val_out, int64_t slot, int lane, const float (&b)[V])
 {
     constexpr int PER = V == 9 ? 576 : (V == 3 && !SIGNED ? 192 : 64);
     float *o = val_out + slot * PER;
     if constexpr (V == 9) {
-        float b[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) b[q] = e >= 0 ? val[e * 9 + q] : 0.f;
         // pieces b00 b10 b01 b11 | b02 b12 b20 b21 | b22   (bij = row i, column j: b[3*i + j])
         *reinterpret_cast<float4 *>(o + lane * 4) = make_float4(b[0], b[3], b[1], b[4]);
         *reinterpret_cast<float4 *>(o + 256 + lane * 4) = make_float4(b[2], b[5], b[6], b[7]);
         o[512 + lane] = b[8];
     } else if constexpr (V == 3 && !SIGNED) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c * 64 + lane] = e >= 0 ? val[e * 3 + c] : 0.f;
+        for (int c = 0; c < 3; ++c) o[c * 64 + lane] = b[c];
     } else {
-        o[lane] = e >= 0 ? val[e] : 0.f;
+        o[lane] = b[0];
+    }
+}
+
+template <int V, bool SIGNED>
+__device__ __forceinline__ void put_values(float *__restrict__ val_out, int64_t slot, int lane, const float *__restrict__ val, int64_t e)
+{
+    if constexpr (V == 3 && SIGNED) {              // val is (nnz,) magnitudes here
+        float b[3] = {e >= 0 ? val[e] : 0.f, 0.f, 0.f};
+        store_values<3, true>(val_out, slot, lane, b);
+    } else {
+        float b[V];
+        get_values<V>(b, val, e);
+        store_values<V, SIGNED>(val_out, slot, lane, b);
     }
 }
 
@@ -119,9 +148,18 @@ k_pack_refill(const int *__restrict__ rowptr, const float *__restrict__ val, con
     const int r = perm[(int64_t)s * 64 + lane];
     const int doff = doff_[s], w = doff_[s + 1] - doff;
     const int64_t e0 = r >= 0 ? rowptr[gs + r] : 0;
-    for (int k = 0; k < w; ++k) {
-        const int j = ent[(int64_t)(doff + k) * 64 + lane];
-        put_values<V, false>(val_out, doff + k, lane, val, j >= 0 ? e0 + j : -1);
+    // four slots per trip: their plan bytes, then their values, are loaded together (independent loads in flight), then
+    // stored -- one slot at a time is two dependent global round trips per slot
+    for (int k0 = 0; k0 < w; k0 += 4) {
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = k0 + u < w ? (int)ent[(int64_t)(doff + k0 + u) * 64 + lane] : -1;
+        float b[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) get_values<V>(b[u], val, j[u] >= 0 ? e0 + j[u] : -1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < w) store_values<V, false>(val_out, doff + k0 + u, lane, b[u]);
     }
 }
 
@@ -379,10 +417,12 @@ k_transpose_sym(const int *__restrict__ rowptr, const int *__restrict__ col, con
         }
         if (at < 0) { atomicOr(not_symmetric, 1); continue; }
         if constexpr (V == 9) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) val_t[(int64_t)at * 9 + 3 * b + a] = val[(int64_t)e * 9 + 3 * a + b];
+            float b[9];
+            get_values<9>(b, val, e);
+            f4u lo = {b[0], b[3], b[6], b[1]}, hi = {b[4], b[7], b[2], b[5]};       // the block, transposed, row-major
+            *reinterpret_cast<f4u *>(val_t + (int64_t)at * 9) = lo;
+            *reinterpret_cast<f4u *>(val_t + (int64_t)at * 9 + 4) = hi;
+            val_t[(int64_t)at * 9 + 8] = b[8];
         } else {
 #pragma unroll
             for (int q = 0; q < V; ++q) val_t[(int64_t)at * V + q] = val[(int64_t)e * V + q];
