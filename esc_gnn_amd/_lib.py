@@ -59,6 +59,7 @@ SIGNATURES = {
     "escat_sell_pack_plan": (ci, [vp, i64, vp, ci, ci, ci, ci, vp, sz, vp, vp]),
     "escat_sell_pack_fill": (ci, [vp, vp, vp, vp, i64, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]),
     "escat_sell_pack_refill": (ci, [vp, vp, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp]),
+    "escat_ingest_coo": (ci, [vp, vp, i64, i64, ci, vp, vp, vp, vp]),
     "escat_row_cover": (ci, [vp, vp, i64, vp, vp]),
     "escat_merge_row_ranges": (i64, [vp, i64, i64, vp, vp]),
     "escat_transpose_sym": (ci, [vp, vp, vp, i64, i64, ci, vp, vp, vp]),

@@ -487,3 +487,70 @@ extern "C" int64_t escat_merge_row_ranges(const int64_t *bounds, int64_t nb, int
     *max_rows = (int32_t)mx;
     return k;
 }
+
+// ------------------------------------------------------------------ COO ingest of the reference's two layouts
+// What the reference's pipeline hands over every step (models/escgnn_data_classes.py:137-142 + PyG collate): int64 COO
+// flagged un-coalesced, P already row-major sorted (process_pyg_data.py:775), Q in block-emission order (:839-857: the
+// nine entries of one 3x3 block in a row, blocks in P's order).  One pass checks the layout and writes the canonical
+// int32 structure; *bad is set when the tensor is anything else (the caller then coalesces the general way).
+__device__ __forceinline__ void fill_rowptr(int *__restrict__ rowptr, long long prev_row, long long row, long long e)
+{
+    for (long long q = prev_row + 1; q <= row; ++q) rowptr[q] = (int)e;
+}
+
+__global__ void __launch_bounds__(256)
+k_coo_sorted_to_csr(const long long *__restrict__ rows, const long long *__restrict__ cols, int64_t nnz, int64_t n,
+                    int *__restrict__ rowptr, int *__restrict__ col32, int *__restrict__ bad)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz) return;
+    const long long r = rows[e], c = cols[e];
+    if (r < 0 || r >= n || c < 0 || c >= n) { atomicOr(bad, 1); return; }
+    const long long pr = e ? rows[e - 1] : -1, pc = e ? cols[e - 1] : -1;
+    if (e && !(r > pr || (r == pr && c > pc))) { atomicOr(bad, 1); return; }
+    if (pr >= n) return;
+    col32[e] = (int)c;
+    if (r != pr) fill_rowptr(rowptr, pr, r, e);
+    if (e == nnz - 1) fill_rowptr(rowptr, r, n, nnz);
+}
+
+__global__ void __launch_bounds__(256)
+k_coo_blocks_to_bsr3(const long long *__restrict__ rows, const long long *__restrict__ cols, int64_t nnzb, int64_t nb,
+                     int *__restrict__ rowptr, int *__restrict__ col32, int *__restrict__ bad)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nnzb) return;
+    const long long r0 = rows[9 * b], c0 = cols[9 * b];
+    if (r0 < 0 || c0 < 0 || r0 % 3 || c0 % 3 || r0 / 3 >= nb || c0 / 3 >= nb) { atomicOr(bad, 1); return; }
+    bool ok = true;
+#pragma unroll
+    for (int q = 1; q < 9; ++q) ok = ok && rows[9 * b + q] == r0 + q / 3 && cols[9 * b + q] == c0 + q % 3;
+    const long long br = r0 / 3, bc = c0 / 3;
+    long long pbr = -1, pbc = -1;
+    if (b) { pbr = rows[9 * (b - 1)] / 3; pbc = cols[9 * (b - 1)] / 3; }
+    if (b && !(br > pbr || (br == pbr && bc > pbc))) ok = false;
+    if (!ok) { atomicOr(bad, 1); return; }
+    if (pbr >= nb || pbr < -1) return;
+    col32[b] = (int)bc;
+    if (br != pbr) fill_rowptr(rowptr, pbr, br, b);
+    if (b == nnzb - 1) fill_rowptr(rowptr, br, nb, nnzb);
+}
+
+extern "C" int escat_ingest_coo(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n, int blocks3,
+                                int32_t *rowptr, int32_t *col32, int32_t *bad, void *stream)
+{
+    if (!rows || !cols || !rowptr || !col32 || !bad) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n <= 0 || nnz <= 0) return fail(ESCAT_EINVAL, "empty operator");
+    if (n >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return fail(ESCAT_ERANGE, "n or nnz >= 2^31 (int32 indices)");
+    if (blocks3) {
+        if (n % 3 || nnz % 9) return fail(ESCAT_EINVAL, "a BSR-3 ingest needs n %% 3 == 0 and nnz %% 9 == 0");
+        const int64_t nnzb = nnz / 9;
+        hipLaunchKernelGGL(k_coo_blocks_to_bsr3, dim3((unsigned)((nnzb + 255) / 256)), dim3(256), 0, S(stream),
+                           (const long long *)rows, (const long long *)cols, nnzb, n / 3, rowptr, col32, bad);
+    } else {
+        hipLaunchKernelGGL(k_coo_sorted_to_csr, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, S(stream),
+                           (const long long *)rows, (const long long *)cols, nnz, n, rowptr, col32, bad);
+    }
+    CHECK_LAUNCH("escat_ingest_coo");
+    return ESCAT_OK;
+}

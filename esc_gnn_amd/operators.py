@@ -480,6 +480,11 @@ class ScatterOperator:
             return None
         dev = A.device
         r, c = idx[0], idx[1]
+        if A.is_cuda and idx.dtype == torch.int64 and n < (1 << 31) and nnz < (1 << 31):
+            fast = ScatterOperator._from_emission_order_gpu(r.contiguous(), c.contiguous(), val, n, nnz, graph_ptr, dev)
+            if fast is not None:
+                return fast
+            # neither layout: fall through to the torch formulation below (which will say so and return None)
         if n % 3 == 0 and nnz % 9 == 0:
             r9, c9 = r.view(-1, 9), c.view(-1, 9)
             a = torch.arange(3, device=dev)
@@ -508,6 +513,53 @@ class ScatterOperator:
             op._try_bsr3()
         op._reorder_if_large()
         return op
+
+    @staticmethod
+    def _from_emission_order_gpu(r, c, val, n, nnz, graph_ptr, dev):
+        """the same check + conversion as one HIP pass per candidate layout (escat_ingest_coo): no torch index ops."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+        gp = None
+        if graph_ptr is not None:
+            gp = torch.as_tensor(graph_ptr, device=dev).to(torch.int64)
+        with torch.cuda.device(dev):
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            tries = ([1] if (n % 3 == 0 and nnz % 9 == 0) else []) + [0]
+            for blocks3 in tries:
+                rows_out = n // 3 if blocks3 else n
+                ne = nnz // 9 if blocks3 else nnz
+                rowptr = torch.empty(rows_out + 1, dtype=torch.int32, device=dev)
+                col32 = torch.empty(ne, dtype=torch.int32, device=dev)
+                bad = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(lib.escat_ingest_coo(vp(r), vp(c), nnz, n, blocks3, vp(rowptr), vp(col32), vp(bad), st),
+                           "escat_ingest_coo")
+                if int(bad.item()):
+                    continue
+                op = ScatterOperator(n, dev)
+                op._graph_ptr = gp
+                v32 = val.to(torch.float32)
+                if blocks3:
+                    parts = op._parts_for(3) if gp is not None and bool((gp % 3 == 0).all()) else None
+                    op._bsr = _Csr(rowptr, col32, v32.reshape(-1, 3, 3).contiguous(), n // 3, parts)
+                    op.bsr_fill = 1.0
+                else:
+                    op._csr = _Csr(rowptr, col32, v32.contiguous(), n, op._parts_for(1))
+                    if n % 3 == 0:
+                        op._maybe_bsr3_from_csr()
+                op._reorder_if_large()
+                return op
+        return None
+
+    def _maybe_bsr3_from_csr(self):
+        """a sorted scalar COO whose size is a multiple of 3 may still be an operator of 3x3 blocks (a coalesced Q): take
+        the general route for the block detection (rare: the reference never coalesces Q)"""
+        c = self._csr
+        rp = c.rowptr.long()
+        rows = torch.repeat_interleave(torch.arange(c.n, device=self.device), rp[1:] - rp[:-1])
+        self._coo = (rows, c.col.long(), c.val)
+        self._try_bsr3()
 
     @staticmethod
     def from_csr(rowptr, col, val, n, validate=True, parts=None) -> "ScatterOperator":

@@ -174,6 +174,15 @@ int escat_sell_pack_refill(const int32_t *rowptr, const float *val, int64_t n, c
                            int values_per_entry, const escat_sell_dims *dims, const void *workspace,
                            size_t workspace_bytes, const int8_t *ent_of_slot, float *val_out, void *stream);
 
+/* COO ingest of the two layouts the reference's pipeline produces (models/escgnn_data_classes.py:137-142: int64 COO,
+ * flagged un-coalesced): blocks3 = 0: entries already row-major sorted and unique (P, process_pyg_data.py:775) ->
+ * rowptr (n + 1) / col32 (nnz); blocks3 = 1: block-emission order (Q, :839-857: nine entries per 3x3 block, row-major
+ * inside, blocks in P's order) -> rowptr (n/3 + 1) / col32 (nnz/9) of the BSR-3 form, whose blocks are the COO values
+ * as they lie.  *bad (device, caller zeroes) is set if the tensor is not in that layout: the outputs are then
+ * meaningless and the caller must coalesce the general way.  One elementwise pass, no sort. */
+int escat_ingest_coo(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n, int blocks3,
+                     int32_t *rowptr, int32_t *col32, int32_t *bad, void *stream);
+
 /* Finding the diagonal blocks of a block-diagonal operator (the graphs of a PyG batch,
  * models/escgnn_data_classes.py:20-27).  escat_row_cover: delta (n + 1 ints, caller zeroes) receives +1 / -1 at the ends
  * of every row's column span; after a prefix sum, a cut after row c is legal iff the sum at c is 0.

@@ -166,3 +166,47 @@ def test_shared_plan_refill_equals_a_fresh_pack():
         assert fresh.dmax == shared.dmax and torch.equal(fresh.val, shared.val)
         assert torch.equal(fresh.lc, shared.lc) and torch.equal(fresh.lane_meta, shared.lane_meta)
         assert torch.equal(fresh.pos_of_row, shared.pos_of_row)
+
+
+def test_gpu_coo_ingest_matches_the_coalesced_structure():
+    """escat_ingest_coo (one HIP pass over the reference's COO layouts: sorted P, block-emission Q, both flagged
+    un-coalesced, int64) gives the index structure of torch's own coalesce -- bit-exact -- and anything else (shuffled
+    entries, duplicates) falls back to the general route with the same result."""
+    from esc_gnn_amd import ScatterOperator, synthetic
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(6, 90, 6, seed=3)
+    N, nnz = b["N"], b["nnz"]
+    rows = np.repeat(np.arange(N), np.diff(b["rowptr"])).astype(np.int64)
+    cols = b["col"].astype(np.int64)
+    P = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(b["pval"]), (N, N))
+    a = np.arange(3)
+    qr = ((3 * rows)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1)
+    qc = ((3 * cols)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1)
+    Q = torch.sparse_coo_tensor(torch.from_numpy(np.stack([qr, qc])), torch.from_numpy(b["blk"].reshape(-1)), (3 * N, 3 * N))
+    assert not P.is_coalesced() and not Q.is_coalesced()
+    opP = ScatterOperator.from_torch(P.to(dev))
+    c = opP.csr()
+    assert np.array_equal(c.rowptr.cpu().numpy(), b["rowptr"]) and np.array_equal(c.col.cpu().numpy(), b["col"])
+    assert np.array_equal(c.val.cpu().numpy(), b["pval"])
+    assert c.n_parts == ScatterOperator.from_torch(P.coalesce().to(dev)).csr().n_parts      # same parts as the general route
+    opQ = ScatterOperator.from_torch(Q.to(dev))
+    assert opQ.has_bsr3
+    q = opQ.bsr3()
+    assert np.array_equal(q.rowptr.cpu().numpy(), b["rowptr"]) and np.array_equal(q.col.cpu().numpy(), b["col"])
+    assert np.array_equal(q.val.cpu().numpy(), b["blk"])
+    # the same structure as torch's coalesce of the scalar COO
+    Qc = Q.coalesce()
+    cs = opQ.csr()
+    rp = cs.rowptr.long().cpu()
+    r2 = torch.repeat_interleave(torch.arange(3 * N), rp[1:] - rp[:-1])
+    assert torch.equal(r2, Qc.indices()[0]) and torch.equal(cs.col.long().cpu(), Qc.indices()[1])
+    assert torch.equal(cs.val.cpu(), Qc.values())
+    # shuffled entries with a duplicate pair: not the fast layout -> coalesce route, same canonical operator
+    perm = torch.randperm(nnz, generator=torch.Generator().manual_seed(0))
+    idx = torch.from_numpy(np.stack([rows, cols]))[:, perm]
+    val = torch.from_numpy(b["pval"])[perm]
+    idx = torch.cat([idx, idx[:, :1]], 1); val = torch.cat([val * 1.0, val[:1] * 0.0])
+    Ps = torch.sparse_coo_tensor(idx, val, (N, N))
+    cs2 = ScatterOperator.from_torch(Ps.to(dev)).csr()
+    assert np.array_equal(cs2.rowptr.cpu().numpy(), b["rowptr"]) and np.array_equal(cs2.col.cpu().numpy(), b["col"])
+    assert np.array_equal(cs2.val.cpu().numpy(), b["pval"])
