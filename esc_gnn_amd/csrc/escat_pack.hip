@@ -514,23 +514,32 @@ k_coo_sorted_to_csr(const long long *__restrict__ rows, const long long *__restr
     if (e == nnz - 1) fill_rowptr(rowptr, r, n, nnz);
 }
 
+// 63 lanes of a wave cover 7 blocks (one entry per lane: every load is one coalesced 504-byte access); the block's
+// first entry and the previous block's reach the other lanes by shuffles.
 __global__ void __launch_bounds__(256)
 k_coo_blocks_to_bsr3(const long long *__restrict__ rows, const long long *__restrict__ cols, int64_t nnzb, int64_t nb,
                      int *__restrict__ rowptr, int *__restrict__ col32, int *__restrict__ bad)
 {
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b >= nnzb) return;
-    const long long r0 = rows[9 * b], c0 = cols[9 * b];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int q = lane % 9, k = lane / 9;
+    const int64_t b = wave * 7 + k;
+    const bool live = lane < 63 && b < nnzb;
+    long long r = -1, c = -1;
+    if (live) { r = rows[9 * b + q]; c = cols[9 * b + q]; }
+    const long long r0 = __shfl(r, lane - q, 64), c0 = __shfl(c, lane - q, 64);
+    long long pr0 = __shfl(r, lane >= 9 ? lane - 9 : 0, 64), pc0 = __shfl(c, lane >= 9 ? lane - 9 : 0, 64);
+    if (!live) return;
+    if (r != r0 + q / 3 || c != c0 + q % 3) { atomicOr(bad, 1); return; }
+    if (q) return;
     if (r0 < 0 || c0 < 0 || r0 % 3 || c0 % 3 || r0 / 3 >= nb || c0 / 3 >= nb) { atomicOr(bad, 1); return; }
-    bool ok = true;
-#pragma unroll
-    for (int q = 1; q < 9; ++q) ok = ok && rows[9 * b + q] == r0 + q / 3 && cols[9 * b + q] == c0 + q % 3;
     const long long br = r0 / 3, bc = c0 / 3;
     long long pbr = -1, pbc = -1;
-    if (b) { pbr = rows[9 * (b - 1)] / 3; pbc = cols[9 * (b - 1)] / 3; }
-    if (b && !(br > pbr || (br == pbr && bc > pbc))) ok = false;
-    if (!ok) { atomicOr(bad, 1); return; }
-    if (pbr >= nb || pbr < -1) return;
+    if (b) {
+        if (!k) { pr0 = rows[9 * (b - 1)]; pc0 = cols[9 * (b - 1)]; }
+        pbr = pr0 / 3; pbc = pc0 / 3;
+        if (pr0 < 0 || !(br > pbr || (br == pbr && bc > pbc))) { atomicOr(bad, 1); return; }
+    }
     col32[b] = (int)bc;
     if (br != pbr) fill_rowptr(rowptr, pbr, br, b);
     if (b == nnzb - 1) fill_rowptr(rowptr, br, nb, nnzb);
@@ -545,7 +554,7 @@ extern "C" int escat_ingest_coo(const int64_t *rows, const int64_t *cols, int64_
     if (blocks3) {
         if (n % 3 || nnz % 9) return fail(ESCAT_EINVAL, "a BSR-3 ingest needs n %% 3 == 0 and nnz %% 9 == 0");
         const int64_t nnzb = nnz / 9;
-        hipLaunchKernelGGL(k_coo_blocks_to_bsr3, dim3((unsigned)((nnzb + 255) / 256)), dim3(256), 0, S(stream),
+        hipLaunchKernelGGL(k_coo_blocks_to_bsr3, dim3((unsigned)((nnzb + 27) / 28)), dim3(256), 0, S(stream),
                            (const long long *)rows, (const long long *)cols, nnzb, n / 3, rowptr, col32, bad);
     } else {
         hipLaunchKernelGGL(k_coo_sorted_to_csr, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, S(stream),
