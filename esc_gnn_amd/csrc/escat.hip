@@ -206,8 +206,12 @@ k_bsr3_step(const int *__restrict__ rowptr, const int *__restrict__ col, const f
     constexpr int GL = 3 * g, RPW = 64 / GL;
     const int lane = threadIdx.x & 63;
     const int sub = lane / GL, l = lane % GL, k = l / 3, a = l % 3;
-    const int64_t waves = (int64_t)gridDim.x * 4;
-    for (int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW; base < nb; base += waves * RPW) {
+    // XCD-aware order: workgroup b runs on XCD b % 8; XCD k walks the k-th eighth of the rows, so the x rows one L2
+    // gathers are its own eighth (+ the band of the relabelled pattern), not the whole vector eight times over
+    const int64_t trips = (nb + 4 * RPW - 1) / (4 * RPW), per_x = (trips + 7) / 8;
+    const int64_t t0 = (blockIdx.x & 7) * per_x, t1 = t0 + per_x < trips ? t0 + per_x : trips;
+    for (int64_t trip = t0 + (blockIdx.x >> 3); trip < t1; trip += gridDim.x >> 3) {
+        const int64_t base = (trip * 4 + (threadIdx.x >> 6)) * RPW;
         const int64_t brow = base + sub;
         const bool live = sub < RPW && brow < nb;
         float acc = 0.f;
@@ -674,6 +678,7 @@ static int grid_for(int64_t work_items, int per_block)
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
     const int64_t cap = 256 * 16;          // 256 CUs x 16 blocks, grid-stride beyond
+    b = (b + 7) & ~(int64_t)7;             // whole rounds of the 8 XCDs (k_bsr3_step's trip order)
     return (int)(b < cap ? b : cap);
 }
 
