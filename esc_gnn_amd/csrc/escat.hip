@@ -206,12 +206,8 @@ k_bsr3_step(const int *__restrict__ rowptr, const int *__restrict__ col, const f
     constexpr int GL = 3 * g, RPW = 64 / GL;
     const int lane = threadIdx.x & 63;
     const int sub = lane / GL, l = lane % GL, k = l / 3, a = l % 3;
-    // XCD-aware order: workgroup b runs on XCD b % 8; XCD k walks the k-th eighth of the rows, so the x rows one L2
-    // gathers are its own eighth (+ the band of the relabelled pattern), not the whole vector eight times over
-    const int64_t trips = (nb + 4 * RPW - 1) / (4 * RPW), per_x = (trips + 7) / 8;
-    const int64_t t0 = (blockIdx.x & 7) * per_x, t1 = t0 + per_x < trips ? t0 + per_x : trips;
-    for (int64_t trip = t0 + (blockIdx.x >> 3); trip < t1; trip += gridDim.x >> 3) {
-        const int64_t base = (trip * 4 + (threadIdx.x >> 6)) * RPW;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW; base < nb; base += waves * RPW) {
         const int64_t brow = base + sub;
         const bool live = sub < RPW && brow < nb;
         float acc = 0.f;
@@ -242,6 +238,114 @@ k_bsr3_step(const int *__restrict__ rowptr, const int *__restrict__ col, const f
                 for (int q = 0; q < ev.n; ++q) emit_one(o, y, ev.e[q].slot, ev.e[q].sign);
             }
         }
+    }
+}
+
+// The same step, staged through LDS (round 2; the default of the multi-launch path).  The lane-group kernel above chains
+// rowptr -> col -> x per lane and keeps 12 bytes per lane in flight: measured 3.6 TB/s at cfg3.  Here a workgroup takes
+// STG_RPB consecutive block rows per trip: their blocks are ONE contiguous range of the value array, copied to LDS with
+// 16-byte non-temporal loads that all go out together (the stream must not evict x from the L2s), the x rows of all
+// those blocks are gathered into LDS at the same time, the rows' offsets ride along; then 8 lanes per row compute all
+// three block rows out of LDS (odd strides: conflict-free).  tools/lds/step_bench.hip: 0.432 -> 0.316 ms per step on
+// a cfg3-shaped operator (5.0 TB/s), the same kernel without any x gather 0.27 ms.
+// A trip whose rows hold more than STG_CAP blocks is computed straight from global memory (same lanes, same order).
+#define STG_RPB 32
+#define STG_CAP 768
+#define STG_NQ ((STG_CAP * 9 + 3) / 4 + 1)
+#define STG_LDS_BYTES ((STG_NQ * 4 + STG_CAP * 3 + STG_RPB + 4) * 4)
+typedef float escat_vf4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_bsr3_step_staged(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
+                   const float *__restrict__ xin, float *__restrict__ yout, int nb, int64_t nnzb,
+                   StepEv ev, float *OUT, int F)
+{
+    constexpr int LPR = 256 / STG_RPB, QPT = (STG_NQ + 255) / 256, EPT = (STG_CAP + 255) / 256;
+    extern __shared__ float stg_lds[];
+    float *vL = stg_lds, *xL = stg_lds + STG_NQ * 4;
+    int *rpL = reinterpret_cast<int *>(xL + STG_CAP * 3);
+    const int trips = (nb + STG_RPB - 1) / STG_RPB;
+    const int64_t nfl = nnzb * 9;
+    for (int trip = blockIdx.x; trip < trips; trip += gridDim.x) {
+        const int r0 = trip * STG_RPB, r1 = r0 + STG_RPB < nb ? r0 + STG_RPB : nb;
+        const int e0 = rowptr[r0], e1 = rowptr[r1], ne = e1 - e0;
+        const bool staged = ne <= STG_CAP;
+        const int64_t f0 = (int64_t)e0 * 9, a0 = f0 & ~(int64_t)3;
+        if (threadIdx.x <= r1 - r0) rpL[threadIdx.x] = rowptr[r0 + threadIdx.x] - e0;
+        if (staged) {
+            const int nq = (int)(((int64_t)e1 * 9 - a0 + 3) >> 2);
+            int c[EPT];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) { const int i = threadIdx.x + 256 * j; c[j] = i < ne ? col[e0 + i] : 0; }
+            float4 v[QPT];
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                const int q = threadIdx.x + 256 * j;
+                const int64_t gq = a0 + 4 * (int64_t)q;
+                if (q < nq) {
+                    if (gq + 4 <= nfl) {
+                        const escat_vf4 t = __builtin_nontemporal_load(reinterpret_cast<const escat_vf4 *>(blk + gq));
+                        v[j] = make_float4(t.x, t.y, t.z, t.w);
+                    } else {                                      // the array's last, partial 16 bytes
+                        v[j].x = blk[gq]; v[j].y = gq + 1 < nfl ? blk[gq + 1] : 0.f; v[j].z = gq + 2 < nfl ? blk[gq + 2] : 0.f; v[j].w = 0.f;
+                    }
+                }
+            }
+            float xr[EPT][3];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const float *xp = xin + (int64_t)c[j] * 3;
+                xr[j][0] = xp[0]; xr[j][1] = xp[1]; xr[j][2] = xp[2];
+            }
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) { const int q = threadIdx.x + 256 * j; if (q < nq) *reinterpret_cast<float4 *>(vL + 4 * q) = v[j]; }
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int i = threadIdx.x + 256 * j;
+                if (i < ne) { xL[3 * i] = xr[j][0]; xL[3 * i + 1] = xr[j][1]; xL[3 * i + 2] = xr[j][2]; }
+            }
+        }
+        __syncthreads();
+        const int lr = threadIdx.x / LPR, row = r0 + lr, k = threadIdx.x % LPR;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (row < r1) {
+            const int i0 = rpL[lr], i1 = rpL[lr + 1];
+            if (staged) {
+                const float *vb = vL + (int)(f0 - a0);
+                for (int i = i0 + k; i < i1; i += LPR) {
+                    const float *b = vb + i * 9; const float *x = xL + 3 * i;
+                    const float x0 = x[0], x1 = x[1], x2 = x[2];
+                    s0 += b[0] * x0 + b[1] * x1 + b[2] * x2;
+                    s1 += b[3] * x0 + b[4] * x1 + b[5] * x2;
+                    s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
+                }
+            } else {
+                for (int i = i0 + k; i < i1; i += LPR) {
+                    const float *b = blk + ((int64_t)e0 + i) * 9; const float *x = xin + (int64_t)col[e0 + i] * 3;
+                    const float x0 = x[0], x1 = x[1], x2 = x[2];
+                    s0 += b[0] * x0 + b[1] * x1 + b[2] * x2;
+                    s1 += b[3] * x0 + b[4] * x1 + b[5] * x2;
+                    s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = LPR / 2; m >= 1; m >>= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        if (row < r1 && k < 3) {
+            const int64_t r = 3 * (int64_t)row + k;
+            float y = k == 0 ? s0 : k == 1 ? s1 : s2;
+            if (MODE == 2) {
+                const float *gg = OUT + r * F;
+                for (int q = 0; q < ev.n; ++q) y += (ev.e[q].sign & 2) ? -gg[ev.e[q].slot] : gg[ev.e[q].slot];
+            }
+            yout[r] = y;
+            if (MODE == 1) {
+                float *o = OUT + r * F;
+                for (int q = 0; q < ev.n; ++q) emit_one(o, y, ev.e[q].slot, ev.e[q].sign);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -678,7 +782,6 @@ static int grid_for(int64_t work_items, int per_block)
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
     const int64_t cap = 256 * 16;          // 256 CUs x 16 blocks, grid-stride beyond
-    b = (b + 7) & ~(int64_t)7;             // whole rounds of the 8 XCDs (k_bsr3_step's trip order)
     return (int)(b < cap ? b : cap);
 }
 
@@ -729,10 +832,28 @@ static int launch_csr_step(int C, int G, const int *rp, const int *ci, const flo
     return ESCAT_OK;
 }
 
+static bool bsr3_step_lanes()          // ESCAT_BSR3_STEP=lanes: the round-1 lane-group kernel (debug aid, tests)
+{
+    const char *e = getenv("ESCAT_BSR3_STEP");          // read per launch: tests switch it inside one process
+    return e && !strcmp(e, "lanes");
+}
+
 template <int MODE>
 static void launch_bsr3_step(int g, const int *rp, const int *ci, const float *blk, const float *xin, float *y,
-                             int64_t nb, const StepEv &ev, float *OUT, int F, hipStream_t st)
+                             int64_t nb, int64_t nnzb, const StepEv &ev, float *OUT, int F, hipStream_t st)
 {
+    if (!bsr3_step_lanes()) {
+        // static trip order: every workgroup of the grid must be resident, so the grid is what the device holds
+        static const int per_cu = [] {
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bsr3_step_staged<MODE>, 256, STG_LDS_BYTES) != hipSuccess || occ < 1) occ = 1;
+            return occ;
+        }();
+        const int64_t trips = (nb + STG_RPB - 1) / STG_RPB, cap = (int64_t)escat_cu_count() * per_cu;
+        hipLaunchKernelGGL((k_bsr3_step_staged<MODE>), dim3((unsigned)(trips < cap ? (trips < 1 ? 1 : trips) : cap)), dim3(256),
+                           STG_LDS_BYTES, st, rp, ci, blk, xin, y, (int)nb, nnzb, ev, OUT, F);
+        return;
+    }
     if (g == 3) hipLaunchKernelGGL((k_bsr3_step<3, MODE>), dim3(grid_for(nb, 4 * 7)), dim3(256), 0, st, rp, ci, blk, xin, y, nb, ev, OUT, F);
     else        hipLaunchKernelGGL((k_bsr3_step<7, MODE>), dim3(grid_for(nb, 4 * 3)), dim3(256), 0, st, rp, ci, blk, xin, y, nb, ev, OUT, F);
 }
@@ -767,7 +888,7 @@ extern "C" int escat_bsr3_spmv_f32(const int32_t *rowptr, const int32_t *col, co
     if (!x || !y) return fail(ESCAT_EINVAL, "x or y is NULL");
     if (nb == 0) return ESCAT_OK;
     StepEv ev; ev.n = 0;
-    launch_bsr3_step<0>(pick_g(nb, nnzb), rowptr, col, blk, x, y, nb, ev, nullptr, 0, S(stream));
+    launch_bsr3_step<0>(pick_g(nb, nnzb), rowptr, col, blk, x, y, nb, nnzb, ev, nullptr, 0, S(stream));
     CHECK_LAUNCH("escat_bsr3_spmv_f32");
     return ESCAT_OK;
 }
@@ -1080,7 +1201,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
         for (int t = 1; t <= T; ++t) {
             rc = step_events(tab, t, &se); if (rc) return rc;
             float *y = (t & 1) ? wa : wb;
-            launch_bsr3_step<1>(g, rowptr, col, blk, xin, y, nb, se, RES, F, st);
+            launch_bsr3_step<1>(g, rowptr, col, blk, xin, y, nb, nnzb, se, RES, F, st);
             xin = y;
         }
     } else {
@@ -1092,7 +1213,7 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
         for (int t = T; t >= 1; --t) {
             rc = step_events(tab, t - 1, &se); if (rc) return rc;
             float *y = (t == 1) ? RES : (((T - t) & 1) ? wa : wb);
-            launch_bsr3_step<2>(g, rowptr, col, blk, xin, y, nb, se, Gm, F, st);
+            launch_bsr3_step<2>(g, rowptr, col, blk, xin, y, nb, nnzb, se, Gm, F, st);
             xin = y;
         }
     }

@@ -210,3 +210,55 @@ def test_gpu_coo_ingest_matches_the_coalesced_structure():
     cs2 = ScatterOperator.from_torch(Ps.to(dev)).csr()
     assert np.array_equal(cs2.rowptr.cpu().numpy(), b["rowptr"]) and np.array_equal(cs2.col.cpu().numpy(), b["col"])
     assert np.array_equal(cs2.val.cpu().numpy(), b["pval"])
+
+
+@pytest.mark.parametrize("graphs,n,k", [(3, 1500, 6), (2, 1100, 40), (1, 37, 5)])
+def test_bsr3_step_staged_vs_oracle(monkeypatch, graphs, n, k):
+    """Multi-launch vector chain through the LDS-staged step kernel (k_bsr3_step_staged, the default) and through the
+    round-1 lane-group kernel (ESCAT_BSR3_STEP=lanes): forward and x.grad against the C oracle.  k = 40 gives trips of
+    32 rows with more than 768 blocks: the kernel's straight-from-global branch."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(graphs, n, k, seed=21)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    if k == 40:
+        assert np.diff(b["rowptr"][::32]).max() > 768
+    op = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    kw = dict(J=3)
+    plan = plan_chain(**kw)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    gq = torch.randn(3 * b["N"], 1, plan.F, generator=torch.Generator().manual_seed(2))
+    ref = co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F)
+    refg = co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T)
+    monkeypatch.setenv("ESCAT_CHAIN_PATH", "multi")
+    outs = []
+    for step in (None, "lanes"):
+        if step:
+            monkeypatch.setenv("ESCAT_BSR3_STEP", step)
+        xq = xv.to(dev).requires_grad_(True)
+        W = get_Batch_Wjxs(xq, op, **kw)
+        W.backward(gq.to(dev))
+        for got, want in ((W, ref), (xq.grad, refg)):
+            got = got.detach().cpu().numpy().reshape(want.shape)
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()       # north_star's bar
+        outs.append(W.detach())
+    assert (outs[0] - outs[1]).abs().max() <= 2e-6 * outs[1].abs().max()
+
+
+def test_bsr3_single_product_staged():
+    """escat_bsr3_spmv_f32 (one torch.sparse.mm of the vector track) runs the staged step kernel too."""
+    from esc_gnn_amd import synthetic
+    from esc_gnn_amd import _lib
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(5, 333, 9, seed=4)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rp, ci, blk = t(b["rowptr"]), t(b["col"]), t(b["blk"])
+    x = torch.randn(3 * b["N"], generator=torch.Generator().manual_seed(3))
+    y = torch.empty(3 * b["N"], device=dev)
+    rc = _lib.load().escat_bsr3_spmv_f32(rp.data_ptr(), ci.data_ptr(), blk.data_ptr(), b["N"], b["nnz"], x.to(dev).data_ptr(),
+                                   y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ev = np.array([[1, 0, 1, -1]], dtype=np.int32)
+    ref = co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], x.numpy(), ev, 1, 1).reshape(-1)
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
