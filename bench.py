@@ -113,7 +113,7 @@ def cpu_baseline(b, n_graphs, n_per_graph, J, threads):
 
 def bench_cfg3(c, dev, t, args, J=6, reps=3):
     """secondary, N = 1 only: BASELINE configs[2] -- one cloud (default 2 M points, k = 16), vector track Q (BSR-3),
-    dyadic J = 6 (T = 64).  The graph does not fit LDS: one step kernel per power (k_bsr3_step), the operator streamed
+    dyadic J = 6 (T = 64).  The graph does not fit LDS: one step kernel per power (k_bsr3_step_staged), the operator streamed
     from HBM every step, rows relabelled breadth-first once at ingest.  HIP-event times of the whole chain, forward and
     backward; the step kernel's roofline uses SURVEY 8d's per-step bytes 4(N+1) + 40 nnz + 24 N."""
     import torch
@@ -138,10 +138,10 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
     tele = float((W.detach().sum(-1).reshape(-1) - xv.detach().reshape(-1)).abs().max())
     step_bytes = 4 * (n + 1) + 40 * nnzb + 24 * n
     return {"workload": f"cfg3: one ellipsoid cloud, {n} points, kNN k=16, Q (BSR-3) dyadic J={J} (T={T}, F={F}), fwd and bwd "
-                        f"chains; multi-launch path (k_bsr3_step), breadth-first relabelling at ingest",
+                        f"chains; multi-launch path (k_bsr3_step_staged), breadth-first relabelling at ingest",
             "nodes": n, "nnz_blocks": nnzb, "fwd_ms": tf, "bwd_ms": tb, "fwd_ms_per_step": tf / T,
             "chains_per_s_fwd_bwd": 1e3 / (tf + tb),
-            "roofline": {"bound": "hbm", "kernel": "k_bsr3_step (one diffusion step)", "bytes_per_step": step_bytes,
+            "roofline": {"bound": "hbm", "kernel": "k_bsr3_step_staged (one diffusion step)", "bytes_per_step": step_bytes,
                          "achieved": step_bytes / (tf / T * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": step_bytes / (tf / T * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "algorithmic bytes of one step (operator + x in + y out) / (forward chain time / T)"},

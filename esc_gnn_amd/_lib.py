@@ -72,6 +72,8 @@ SIGNATURES = {
     "escat_lookup3": (ctypes.c_uint32, [ctypes.c_char_p, sz, ctypes.c_uint32]),
     "escat_build_workspace_bytes": (sz, [i64, ci, ci]),
     "escat_build_knn_P": (ci, [vp, vp, ci, i64, ci, ci, vp, vp, vp, i64, vp, vp, sz, vp]),
+    "escat_build_grid_workspace_bytes": (sz, [i64, ci]),
+    "escat_build_knn_P_grid": (ci, [vp, i64, ci, vp, vp, vp, i64, vp, vp, sz, vp]),
     "escat_build_frames": (ci, [vp, vp, vp, i64, ci, ctypes.c_float, ci, ctypes.c_float, ci, ci, ci, vp, vp, vp]),
     "escat_build_frames_ex": (ci, [vp, vp, vp, i64, ci, ctypes.c_float, ci, ctypes.c_float, ci, ci, ci, ci, ctypes.c_float, vp, vp, vp]),
     "escat_build_Q_bsr3": (ci, [vp, vp, vp, vp, i64, ci, ci, vp, vp]),

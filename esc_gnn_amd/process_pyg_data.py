@@ -66,6 +66,31 @@ def frames_and_Q(rowptr, col, pval, pos, kernel_kwargs, use_mean_recentering=Fal
     return frames, blk
 
 
+def _knn_P_grid_batch(pos, gp, k, lib, dev):
+    """escat_build_knn_P_grid per cloud (any size), results joined with global column ids."""
+    rps, cols, vals, base = [], [], [], 0
+    for g in range(len(gp) - 1):
+        n = gp[g + 1] - gp[g]
+        p = pos[gp[g]:gp[g + 1]].contiguous()
+        cap = n * (2 * k + 1)
+        rp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        co = torch.empty(cap, dtype=torch.int32, device=dev)
+        va = torch.empty(cap, dtype=torch.float32, device=dev)
+        nnz_d = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.escat_build_grid_workspace_bytes(n, k) // 4, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.escat_build_knn_P_grid(_ptr(p), n, k, _ptr(rp), _ptr(co), _ptr(va), cap, _ptr(nnz_d), _ptr(ws),
+                                                  ws.numel() * 4, _stream(dev)), "escat_build_knn_P_grid")
+        nnz = int(nnz_d.item())
+        if nnz < 0 or base + nnz >= 2 ** 31:
+            raise OverflowError("escat: more than 2^31 nonzeros")
+        rps.append(rp[:-1] + base if g + 1 < len(gp) - 1 else rp + base)
+        cols.append(co[:nnz] + gp[g]); vals.append(va[:nnz])
+        base += nnz
+        del ws
+    return torch.cat(rps).contiguous(), torch.cat(cols).contiguous(), torch.cat(vals).contiguous()
+
+
 def build_PQ_batch(pos: torch.Tensor, graph_ptr: torch.Tensor, k: int, local_pca_kernel_fn_kwargs: Dict[str, Any],
                    use_mean_recentering: bool = False, enforce_sign: bool = True,
                    sing_vect_align_method: str = "column_dot", max_graph_nodes: Optional[int] = None,
@@ -87,18 +112,23 @@ def build_PQ_batch(pos: torch.Tensor, graph_ptr: torch.Tensor, k: int, local_pca
         max_graph_nodes = true_max
     elif max_graph_nodes < true_max:                   # it sizes the kernels' LDS bitmap: too small would overflow LDS
         raise ValueError(f"escat: max_graph_nodes={max_graph_nodes} but the largest graph has {true_max} nodes")
-    cap = N * (2 * k + 1)
-    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
-    col = torch.empty(cap, dtype=torch.int32, device=dev)
-    pval = torch.empty(cap, dtype=torch.float32, device=dev)
-    nnz_d = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws = torch.empty(lib.escat_build_workspace_bytes(N, B, k) // 4, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.escat_build_knn_P(_ptr(pos), _ptr(graph_ptr), B, N, max_graph_nodes, k, _ptr(rowptr), _ptr(col),
-                                         _ptr(pval), cap, _ptr(nnz_d), _ptr(ws), ws.numel() * 4, _stream(dev)),
-                   "escat_build_knn_P")
-    nnz = int(nnz_d.item())
-    col, pval = col[:nnz], pval[:nnz]
+    if max_graph_nodes * ((max_graph_nodes + 31) // 32) * 4 > 150 * 1024:
+        # beyond the LDS adjacency bitmap of escat_build_knn_P (~1090 nodes): the grid builder, one cloud at a time
+        rowptr, col, pval = _knn_P_grid_batch(pos, graph_ptr.tolist(), k, lib, dev)
+        nnz = col.numel()
+    else:
+        cap = N * (2 * k + 1)
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(cap, dtype=torch.int32, device=dev)
+        pval = torch.empty(cap, dtype=torch.float32, device=dev)
+        nnz_d = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.escat_build_workspace_bytes(N, B, k) // 4, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.escat_build_knn_P(_ptr(pos), _ptr(graph_ptr), B, N, max_graph_nodes, k, _ptr(rowptr), _ptr(col),
+                                             _ptr(pval), cap, _ptr(nnz_d), _ptr(ws), ws.numel() * 4, _stream(dev)),
+                       "escat_build_knn_P")
+        nnz = int(nnz_d.item())
+        col, pval = col[:nnz], pval[:nnz]
     frames, blk = frames_and_Q(rowptr, col, pval, pos, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
                                sing_vect_align_method)
     out = {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk, "frames": frames, "nnz": nnz, "graph_ptr": graph_ptr,

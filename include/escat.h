@@ -323,6 +323,16 @@ int escat_build_knn_P(const float *pos, const int32_t *graph_ptr, int n_graphs, 
                       int max_graph_nodes, int k, int32_t *rowptr, int32_t *col, float *pval,
                       int64_t cap, int32_t *nnz_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same outputs for ONE point cloud of any size (cfg3: a 2 M-point cloud; data_processing/ellipsoid_data_classes.py:
+ * 209-211 builds knn_graph + to_undirected over the whole cloud): the points are binned into a uniform grid in HBM
+ * (cell edge chosen from the measured occupancy, ~4 points per occupied cell), every point searches rings of cells
+ * until its k-th neighbour lies inside the scanned cube -- exact kNN, fp64 distances, ties to the smaller index, i.e.
+ * the lists of escat_build_knn_P -- and the symmetrisation runs on the lists themselves instead of an LDS bitmap.
+ * Columns are local to the cloud.  Synchronises `stream` (it reads the bounding box and the occupancy back). */
+size_t escat_build_grid_workspace_bytes(int64_t n_nodes, int k);
+int escat_build_knn_P_grid(const float *pos, int64_t n_nodes, int k, int32_t *rowptr, int32_t *col, float *pval,
+                           int64_t cap, int32_t *nnz_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Local-PCA frames O_i (get_C_i_dict :330-451 + get_l_singular_vecs :238-286):
  * frames[i][a][c] = component a of the c-th left singular vector of
  * C_i = (w_j (v_j - v_i))_j over the neighbours j of i in the CSR pattern

@@ -385,3 +385,91 @@ def test_graph_construction_paths_vs_reference_goldens(tag, gc, kw):
     assert np.array_equal(obj.edge_index.cpu().numpy(), g[f"gc_{tag}_edge_index"])
     W = get_Batch_Wjxs(torch.from_numpy(pos).cuda().reshape(-1, 1), obj.Q, J=2)
     assert W.shape == (3 * pos.shape[0], 1, 4) and torch.isfinite(W).all()
+
+
+# ------------------------------------------------------------------ clouds beyond the LDS bitmap: the grid builder
+def _grid_P(pos_np, k):
+    from esc_gnn_amd import _lib
+    from esc_gnn_amd.process_pyg_data import _knn_P_grid_batch
+    dev = torch.device("cuda:0")
+    pos = torch.from_numpy(np.ascontiguousarray(pos_np, dtype=np.float32)).to(dev)
+    rp, co, va = _knn_P_grid_batch(pos, [0, pos.shape[0]], k, _lib.load(), dev)
+    return rp.cpu().numpy(), co.cpu().numpy(), va.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,k", [(900, 10), (700, 16), (64, 5), (5, 8), (1, 3)])
+def test_grid_builder_equals_bitmap_builder(n, k):
+    """escat_build_knn_P_grid (uniform grid in HBM, any size) against escat_build_knn_P (brute force + LDS bitmap) on
+    clouds both can take: rowptr, col and the lazy-walk values bit for bit (same fp64 distances, same tie rule)."""
+    from esc_gnn_amd import synthetic
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    dev = torch.device("cuda:0")
+    pos = synthetic.ellipsoid_clouds(1, n, seed=31 + n)[0] if n >= 5 else np.random.RandomState(n).randn(n, 3).astype(np.float32)
+    pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(n, 3)
+    rp, co, va = _grid_P(pos, k)
+    if n > k:
+        b = build_PQ_batch(torch.from_numpy(pos).to(dev), torch.tensor([0, n], dtype=torch.int32), k, {'kernel': 'gaussian'})
+        assert np.array_equal(rp, b["rowptr"].cpu().numpy()) and np.array_equal(co, b["col"].cpu().numpy())
+        assert np.array_equal(va, b["pval"].cpu().numpy())
+    if n <= k:                       # fewer than k other points: every point is linked to all others
+        assert np.array_equal(np.diff(rp), np.full(n, n)) and np.array_equal(co, np.tile(np.arange(n), n))
+
+
+@pytest.mark.parametrize("shape", ["ellipsoid", "cube", "line", "duplicates"])
+def test_grid_builder_large_clouds_vs_kdtree(shape):
+    """30 000-point clouds (beyond the bitmap builder) against scipy's cKDTree + the host symmetrisation of
+    synthetic.knn_sym_csr: identical CSR structure and values -- on a surface, in a volume, on a line (two degenerate
+    axes) and with repeated points (ties resolved by index: compared through distances there)."""
+    from esc_gnn_amd import synthetic
+    n, k = 30000, 16
+    rng = np.random.RandomState(5)
+    if shape == "ellipsoid":
+        pos = synthetic.single_cloud(n, 2, workers=1)["pos"]
+    elif shape == "cube":
+        pos = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    elif shape == "line":
+        pos = np.zeros((n, 3), np.float32); pos[:, 1] = rng.permutation(n).astype(np.float32) * 0.25 + 3.0
+    else:
+        pos = rng.uniform(-1, 1, (n // 2, 3)).astype(np.float32); pos = np.concatenate([pos, pos])[rng.permutation(n)]
+    rp, co, va = _grid_P(pos, k)
+    assert rp[0] == 0 and rp[-1] == co.shape[0] and np.all(np.diff(rp) >= k + 1)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    # sorted, unique, symmetric, diagonal present
+    key = rows.astype(np.int64) * n + co
+    assert np.all(np.diff(key) > 0)
+    assert np.array_equal(np.sort(co.astype(np.int64) * n + rows), key)
+    assert np.all(np.isin(np.arange(n, dtype=np.int64) * (n + 1), key))
+    assert np.array_equal(va, synthetic.lazy_walk_values(rp.astype(np.int64), co.astype(np.int64)))
+    if shape != "duplicates":
+        rp_ref, co_ref = synthetic.knn_sym_csr(pos, k, workers=1)
+        assert np.array_equal(rp, rp_ref) and np.array_equal(co, co_ref)
+    else:
+        # with exact ties the kd-tree's choice among equidistant points is its own; compare the k-th distances instead
+        from scipy.spatial import cKDTree
+        p64 = pos.astype(np.float64)
+        dk, _ = cKDTree(p64).query(p64, k=k + 1)
+        d = np.linalg.norm(p64[rows] - p64[co], axis=1)
+        # every point's row holds at least its k nearest: the (k)-th smallest off-diagonal distance in the row <= kd-tree's
+        order = np.lexsort((d, rows))
+        dsorted = d[order]
+        kth = dsorted[rp[:-1] + k]                    # position 0 is the diagonal (d = 0)... duplicates also have d = 0
+        assert np.all(kth <= dk[:, k] + 1e-12)
+
+
+def test_grid_builder_through_build_PQ_batch():
+    """build_PQ_batch takes the grid route by itself for clouds beyond ~1090 nodes (two clouds here: global column
+    ids, one rowptr) and the result runs through the scattering chain (row-stochastic P: the bands of a constant vanish)."""
+    from esc_gnn_amd import synthetic, get_Batch_Wjxs
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    dev = torch.device("cuda:0")
+    pos = np.concatenate([synthetic.single_cloud(1500, 2, workers=1)["pos"], synthetic.single_cloud(2100, 2, seed=3, workers=1)["pos"] + 10.0])
+    gp = torch.tensor([0, 1500, 3600], dtype=torch.int32)
+    b = build_PQ_batch(torch.from_numpy(pos).to(dev), gp, 12, {'kernel': 'gaussian'})
+    rp, co = b["rowptr"].cpu().numpy(), b["col"].cpu().numpy()
+    ref = [synthetic.knn_sym_csr(pos[a:z], 12, workers=1) for a, z in ((0, 1500), (1500, 3600))]
+    assert np.array_equal(rp, np.concatenate([ref[0][0][:-1], ref[1][0] + ref[0][0][-1]]))
+    assert np.array_equal(co, np.concatenate([ref[0][1], ref[1][1] + 1500]))
+    x = torch.ones(3600, 2, device=dev)
+    W = get_Batch_Wjxs(x, b["P"], J=3)
+    assert W[..., :-1].abs().max() < 1e-5 and (W[..., -1] - 1).abs().max() < 1e-5
+    assert b["blk"].shape == (co.shape[0], 3, 3) and torch.isfinite(b["blk"]).all()
