@@ -136,6 +136,19 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
         if r >= 1:
             tf += e[0].elapsed_time(e[1]) / reps; tb += e[1].elapsed_time(e[2]) / reps
     tele = float((W.detach().sum(-1).reshape(-1) - xv.detach().reshape(-1)).abs().max())
+    # the same cloud's operators built by the product's own builder (grid kNN + P + local-PCA frames + Q blocks, all on
+    # the GPU), timed, its pattern checked against the host kd-tree's that fed the chain above
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    del W, g
+    gp = torch.tensor([0, n], dtype=torch.int32)
+    pos_d = t(c["pos"])
+    build_s = []
+    for r in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        bb = build_PQ_batch(pos_d, gp, 16, {'kernel': 'epanechnikov', 'r_cut': 5.0})
+        torch.cuda.synchronize(); build_s.append(time.perf_counter() - t0)
+    same = bool(torch.equal(bb["rowptr"].cpu(), torch.from_numpy(c["rowptr"])) and torch.equal(bb["col"].cpu(), torch.from_numpy(c["col"])))
+    del bb
     step_bytes = 4 * (n + 1) + 40 * nnzb + 24 * n
     return {"workload": f"cfg3: one ellipsoid cloud, {n} points, kNN k=16, Q (BSR-3) dyadic J={J} (T={T}, F={F}), fwd and bwd "
                         f"chains; multi-launch path (k_bsr3_step_staged), breadth-first relabelling at ingest",
@@ -145,7 +158,10 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
                          "achieved": step_bytes / (tf / T * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": step_bytes / (tf / T * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "algorithmic bytes of one step (operator + x in + y out) / (forward chain time / T)"},
-            "telescoping_max_abs_err": tele, "host_knn_s": c["gen_s"], "ingest_and_relabel_s": ingest_s}
+            "telescoping_max_abs_err": tele, "host_knn_s": c["gen_s"], "ingest_and_relabel_s": ingest_s,
+            "gpu_build": {"what": "escat_build_knn_P_grid + frames + Q blocks + operator ingest of the same cloud (process_pyg_data's "
+                                  "builder on the GPU)", "seconds": build_s[1], "seconds_first_call": build_s[0],
+                          "pattern_equal_to_host_kdtree": same}}
 
 
 def main():

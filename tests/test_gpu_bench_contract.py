@@ -31,6 +31,7 @@ def test_bench_json_contract():
     assert rf["frac"] <= 1.0 and "lds" in rf and rf["lds"]["frac"] <= 1.0 and "algorithmic_GBs" in rf
     c3 = d["cfg3"]
     assert c3["nodes"] == 30000 and c3["fwd_ms"] > 0 and c3["roofline"]["bound"] == "hbm" and c3["telescoping_max_abs_err"] < 1e-4
+    assert c3["gpu_build"]["pattern_equal_to_host_kdtree"] is True and c3["gpu_build"]["seconds"] > 0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
