@@ -354,3 +354,33 @@ def write_operator_file(path, graphs, op_keys=("P", "Q")):
                 f.write(f"edge_index/{idx}/values", _np(d["edge_index"]).astype(np.int64))
             if "edge_weight" in d:
                 f.write(f"edge_weight/{idx}/values", _np(d["edge_weight"]))
+
+
+def merge_h5_files(path, shard_paths, remove_shards=True):
+    """merge_hdf5_files of scripts/python/parallel_process_dataset.py:239-253: every group and dataset of the shard files
+    (one per worker / rank, disjoint sample indices) copied into ONE file; a dataset name already present is kept as it
+    is, as the reference does.  Shards may be of either kind open_h5 reads; the output is written by H5Writer."""
+    def walk(node, prefix):
+        for key in node.keys():
+            child = node[key]
+            name = f"{prefix}/{key}" if prefix else key
+            if hasattr(child, "keys"):
+                yield from walk(child, name)
+            else:
+                yield name, child
+    seen = set()
+    with H5Writer(path) as out:
+        for sp in shard_paths:
+            f = open_h5(sp)
+            try:
+                for name, ds in walk(f, ""):
+                    if name in seen:
+                        continue
+                    seen.add(name)
+                    out.write(name, np.asarray(ds[...]))
+            finally:
+                f.close()
+    if remove_shards:
+        for sp in shard_paths:
+            os.remove(sp)
+    return len(seen)

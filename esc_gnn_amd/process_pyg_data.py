@@ -290,11 +290,13 @@ def process_pyg_data(
 
 def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k: int,
                        local_pca_kernel_fn_kwargs: Dict[str, Any], hdf5_tensor_dtype: str = "float16",
-                       chunk_graphs: int = 16384, store_frames: bool = False, **build_kwargs) -> Dict[str, Any]:
+                       chunk_graphs: int = 16384, store_frames: bool = False, index_offset: int = 0,
+                       **build_kwargs) -> Dict[str, Any]:
     """
     The P/Q -> HDF5 loop of scripts/python/generate_ellipsoid_dataset.py:1165-1213 for a whole dataset: graphs are
     built on the GPU in chunks (build_PQ_batch), the per-graph COO arrays of the reference layout are formed on the
     GPU for the whole chunk, copied to the host once and written by esc_gnn_amd.hdf5_min (atomic rename at the end).
+    index_offset: sample index of the first graph (a shard of a larger dataset: write_dataset_hdf5_sharded).
     store_frames=True adds /frames/{idx}/values, the (n, 3, 3) fp32 local frames -- an extension of the layout (the
     reference's reader never looks at it) that lets esc_gnn_amd.store load the vector operator in factored form.
     """
@@ -330,7 +332,7 @@ def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k:
             for g in range(g1 - g0):
                 e0, e1 = int(eoff[g]), int(eoff[g + 1])
                 ng = int(gpn[g + 1] - gpn[g])
-                idx = g0 + g
+                idx = index_offset + g0 + g
                 f.write(f"P/{idx}/indices", P_idx[:, e0:e1])
                 f.write(f"P/{idx}/values", P_val[e0:e1])
                 f.write(f"P/{idx}/size", np.array([ng, ng], dtype=np.int64))
@@ -340,3 +342,41 @@ def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k:
                 if store_frames:
                     f.write(f"frames/{idx}/values", fr[int(gpn[g]):int(gpn[g + 1])])
     return {"graphs": B, "nnz": total_nnz, "path": path}
+
+
+def write_dataset_hdf5_sharded(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k: int,
+                               local_pca_kernel_fn_kwargs: Dict[str, Any], rank: Optional[int] = None,
+                               world: Optional[int] = None, merge: bool = True, **kwargs) -> Dict[str, Any]:
+    """
+    The dataset build over several GPUs (scripts/python/parallel_process_dataset.py:239-330 does it with a
+    process pool and temp files): graphs are independent, so rank r builds the contiguous range dist_utils.graph_shard
+    gives it and writes `path + f'.shard{r}'` with GLOBAL sample indices -- no collective on the data path; after a
+    barrier rank 0 merges the shards into `path` (hdf5_min.merge_h5_files) and removes them.  rank / world default to
+    the torch.distributed environment; every rank passes the same pos / graph_ptr (or at least its own range of pos
+    rows at their global positions).
+    """
+    from .dist_utils import env_rank_world, graph_shard
+    from .hdf5_min import merge_h5_files
+    if rank is None or world is None:
+        rank, _, world = env_rank_world()
+    gp_all = graph_ptr.to(torch.int64).cpu()
+    B = gp_all.numel() - 1
+    g0, g1 = graph_shard(B, rank, world)
+    shard = f"{path}.shard{rank}"
+    n0, n1 = int(gp_all[g0]), int(gp_all[g1])
+    info = {"graphs": 0, "nnz": 0, "path": shard}
+    if g1 > g0:
+        info = write_dataset_hdf5(shard, pos[n0:n1], gp_all[g0:g1 + 1] - n0, k, local_pca_kernel_fn_kwargs,
+                                  index_offset=g0, **kwargs)
+    else:
+        from .hdf5_min import H5Writer
+        with H5Writer(shard):
+            pass
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    info.update(rank=rank, world=world, shard_range=(g0, g1))
+    if merge and rank == 0:
+        info["merged_datasets"] = merge_h5_files(path, [f"{path}.shard{r}" for r in range(world)])
+        info["path"] = path
+    return info

@@ -7,6 +7,7 @@ Q values: the reference takes O_i from a fp32 LAPACK SVD of C_i, the kernel from
 C_i C_i^T; both are exact up to rounding, but where two singular values nearly coincide the frame is ill-conditioned
 (SURVEY.md §7), so blocks are compared with a gap-aware tolerance and globally through the invariants.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -473,3 +474,30 @@ def test_grid_builder_through_build_PQ_batch():
     W = get_Batch_Wjxs(x, b["P"], J=3)
     assert W[..., :-1].abs().max() < 1e-5 and (W[..., -1] - 1).abs().max() < 1e-5
     assert b["blk"].shape == (co.shape[0], 3, 3) and torch.isfinite(b["blk"]).all()
+
+
+def test_sharded_dataset_build_equals_single_file(tmp_path):
+    """SURVEY 8e, operator build over ranks: two ranks' shards (built one after the other here, global sample indices,
+    no exchange) merged by rank 0 hold exactly the datasets of the one-process build."""
+    from esc_gnn_amd.process_pyg_data import write_dataset_hdf5, write_dataset_hdf5_sharded
+    from esc_gnn_amd.hdf5_min import open_h5
+    from esc_gnn_amd import synthetic
+    dev = _dev()
+    sizes = [40, 33, 64, 21, 57, 48, 30]
+    pos = torch.from_numpy(np.concatenate([synthetic.ellipsoid_clouds(1, n, seed=7 + n)[0] for n in sizes])).to(dev)
+    gp = torch.from_numpy(np.cumsum([0] + sizes).astype(np.int32))
+    kw = {"kernel": "gaussian", "gaussian_eps": 0.1}
+    one, many = str(tmp_path / "one.h5"), str(tmp_path / "many.h5")
+    write_dataset_hdf5(one, pos, gp, 5, kw, chunk_graphs=3)
+    i1 = write_dataset_hdf5_sharded(many, pos, gp, 5, kw, rank=1, world=2, chunk_graphs=3)
+    i0 = write_dataset_hdf5_sharded(many, pos, gp, 5, kw, rank=0, world=2, chunk_graphs=3)
+    assert i0["shard_range"] == (0, 4) and i1["shard_range"] == (4, 7) and i0["merged_datasets"] == 6 * 7
+    assert not os.path.exists(many + ".shard0") and not os.path.exists(many + ".shard1")
+    fa, fb = open_h5(one), open_h5(many)
+    for op in ("P", "Q"):
+        assert sorted(fa[op].keys(), key=int) == sorted(fb[op].keys(), key=int) == [str(i) for i in range(7)]
+        for i in range(7):
+            for d in ("indices", "values", "size"):
+                x, y = fa[op][str(i)][d][...], fb[op][str(i)][d][...]
+                assert x.dtype == y.dtype and np.array_equal(x, y), (op, i, d)
+    fa.close(); fb.close()

@@ -142,3 +142,29 @@ def test_classic_reader_rejects_garbage(tmp_path):
     p.write_bytes(b"not hdf5" * 10)
     with pytest.raises(ValueError):
         open_h5(str(p))
+
+
+def test_merge_of_shard_files(tmp_path):
+    """merge_h5_files (parallel_process_dataset.py:239-253): shards with disjoint sample indices -- one written by this
+    package, one in the classic libhdf5 form -- become one file; a name present twice keeps its first copy."""
+    import numpy as np
+    from tests.h5_classic_writer import write_classic
+    from esc_gnn_amd.hdf5_min import H5Writer, merge_h5_files, open_h5
+    rng = np.random.RandomState(1)
+    a = {f"P/{i}/values": rng.rand(4 + i).astype(np.float16) for i in range(3)}
+    a.update({f"P/{i}/size": np.array([9, 9], dtype=np.int64) for i in range(3)})
+    b = {f"P/{i}/values": rng.rand(4 + i).astype(np.float16) for i in range(3, 7)}
+    b["P/0/values"] = np.zeros(2, np.float16)                       # clashes with shard 0: must be ignored
+    b["Q/3/indices"] = rng.randint(0, 99, size=(2, 30)).astype(np.int64)
+    p0, p1, out = str(tmp_path / "s0.h5"), str(tmp_path / "s1.h5"), str(tmp_path / "all.h5")
+    with H5Writer(p0) as f:
+        for k, v in a.items():
+            f.write(k, v)
+    write_classic(p1, b)
+    n = merge_h5_files(out, [p0, p1])
+    assert n == len(a) + len(b) - 1 and not os.path.exists(p0) and not os.path.exists(p1)
+    f = open_h5(out)
+    assert sorted(f["P"].keys(), key=int) == [str(i) for i in range(7)] and list(f["Q"].keys()) == ["3"]
+    for k, v in {**b, **a}.items():
+        assert np.array_equal(f[k][...], v) and f[k][...].dtype == v.dtype, k
+    f.close()
