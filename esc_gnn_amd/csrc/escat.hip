@@ -349,6 +349,116 @@ k_bsr3_step_staged(const int *__restrict__ rowptr, const int *__restrict__ col, 
     }
 }
 
+// The scalar step staged the same way (north_star's "CSR SpMM ... with multi-column feature tiles staged in LDS"): a trip
+// is RPB consecutive rows, their column / value ranges are contiguous and stream in with every load of the workgroup
+// in flight at once, the x rows (C floats each) of all entries are gathered into LDS alongside, then 256 / RPB lanes
+// per row reduce out of LDS.  VP as in k_csr_step.
+template <int C> struct StgCsr { static constexpr int RPB = C <= 4 ? 64 : 32, CAP = RPB * 24; };
+template <int C, int VP> constexpr int stg_csr_lds_bytes()
+{
+    return (StgCsr<C>::CAP * ((VP == 3 ? 3 : 1) + C + (VP == 4 ? 1 : 0)) + StgCsr<C>::RPB + 4) * 4;
+}
+
+template <int C, int MODE, int VP>
+__global__ void __launch_bounds__(256)
+k_csr_step_staged(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ val,
+                  const float *__restrict__ xin, int ldx, float *__restrict__ yout, int ldy, int n,
+                  StepEv ev, float *OUT, int64_t ld_row, int F)
+{
+    constexpr int RPB = StgCsr<C>::RPB, CAP = StgCsr<C>::CAP, LPR = 256 / RPB, EPT = CAP / 256, NV = VP == 3 ? 3 : 1;
+    extern __shared__ float stg_lds[];
+    float *vL = stg_lds, *xL = vL + CAP * NV;
+    unsigned *cL = reinterpret_cast<unsigned *>(xL + CAP * C);
+    int *rpL = reinterpret_cast<int *>(cL + (VP == 4 ? CAP : 0));
+    const int trips = (n + RPB - 1) / RPB;
+    for (int trip = blockIdx.x; trip < trips; trip += gridDim.x) {
+        const int r0 = trip * RPB, r1 = r0 + RPB < n ? r0 + RPB : n;
+        const int e0 = rowptr[r0], e1 = rowptr[r1], ne = e1 - e0;
+        const bool staged = ne <= CAP;
+        if (threadIdx.x <= r1 - r0) rpL[threadIdx.x] = rowptr[r0 + threadIdx.x] - e0;
+        if (staged) {
+            unsigned cw[EPT]; float vv[EPT][NV];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int i = threadIdx.x + 256 * j;
+                const bool ok = i < ne;
+                cw[j] = ok ? (unsigned)__builtin_nontemporal_load(col + e0 + i) : 0u;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) vv[j][q] = ok ? __builtin_nontemporal_load(val + ((int64_t)e0 + i) * NV + q) : 0.f;
+            }
+            float xr[EPT][C];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const float *x = xin + (int64_t)(VP == 4 ? (cw[j] & 0x1fffffffu) : cw[j]) * ldx;
+#pragma unroll
+                for (int c = 0; c < C; ++c) xr[j][c] = x[c];
+            }
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int i = threadIdx.x + 256 * j;
+                if (i < ne) {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) vL[i * NV + q] = vv[j][q];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) xL[i * C + c] = xr[j][c];
+                    if (VP == 4) cL[i] = cw[j];
+                }
+            }
+        }
+        __syncthreads();
+        const int lr = threadIdx.x / LPR, row = r0 + lr, k = threadIdx.x % LPR;
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        if (row < r1) {
+            const int i0 = rpL[lr], i1 = rpL[lr + 1];
+            for (int i = i0 + k; i < i1; i += LPR) {
+                unsigned w = 0u; float v3[NV]; const float *x;
+                if (staged) {
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) v3[q] = vL[i * NV + q];
+                    if (VP == 4) w = cL[i];
+                    x = xL + i * C;
+                } else {
+                    w = (unsigned)col[e0 + i];
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) v3[q] = val[((int64_t)e0 + i) * NV + q];
+                    x = xin + (int64_t)(VP == 4 ? (w & 0x1fffffffu) : w) * ldx;
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v;
+                    if constexpr (VP == 4) v = __uint_as_float(__float_as_uint(v3[0]) | ((w << (2 - c)) & 0x80000000u));
+                    else if constexpr (VP == 3) v = v3[c % 3];
+                    else v = v3[0];
+                    acc[c] += v * x[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = group_sum<LPR>(acc[c]);
+        if (row < r1) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (c % LPR != k) continue;         // lane c % LPR of the row's group owns channel c
+                float y = acc[c];
+                if (MODE == 2) {
+                    const float *g = OUT + (int64_t)row * ld_row + (int64_t)c * F;
+                    for (int q = 0; q < ev.n; ++q)
+                        if (ev.e[q].chan < 0 || ev.e[q].chan == c) y += (ev.e[q].sign & 2) ? -g[ev.e[q].slot] : g[ev.e[q].slot];
+                }
+                yout[(int64_t)row * ldy + c] = y;
+                if (MODE == 1) {
+                    float *o = OUT + (int64_t)row * ld_row + (int64_t)c * F;
+                    for (int q = 0; q < ev.n; ++q)
+                        if (ev.e[q].chan < 0 || ev.e[q].chan == c) emit_one(o, y, ev.e[q].slot, ev.e[q].sign);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ multi-launch path on a packed operator (large graphs)
 // "SELL-64, global columns": rows sorted by length inside windows of a few thousand rows and cut into slices of 64;
 // slice values slot-major exactly as in the per-part pack (escat_sell), one 32-bit GLOBAL block column per slot
@@ -810,11 +920,44 @@ static void launch_csr_step_G(int G, int grid_rows_hint, const int *rp, const in
     else             hipLaunchKernelGGL((k_csr_step<C, 16, MODE>), dim3(grid_for(n, 16)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F);
 }
 
+static bool step_lanes(const char *name)          // ESCAT_CSR_STEP / ESCAT_BSR3_STEP = lanes: the round-1 lane-group kernels
+{
+    const char *e = getenv(name);                  // read per launch: tests switch it inside one process
+    return e && !strcmp(e, "lanes");
+}
+
+template <int C, int MODE, int VP>
+static void launch_csr_step_staged(const int *rp, const int *ci, const float *v, const float *xin, int ldx, float *y, int ldy,
+                                   int64_t n, const StepEv &ev, float *OUT, int64_t ld_row, int F, hipStream_t st)
+{
+    constexpr int lds = stg_csr_lds_bytes<C, VP>();
+    // static trip order: every workgroup of the grid must be resident, so the grid is what the device holds
+    static const int per_cu = [] {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_csr_step_staged<C, MODE, VP>, 256, lds) != hipSuccess || occ < 1) occ = 1;
+        return occ;
+    }();
+    const int64_t trips = (n + StgCsr<C>::RPB - 1) / StgCsr<C>::RPB, cap = (int64_t)escat_cu_count() * per_cu;
+    hipLaunchKernelGGL((k_csr_step_staged<C, MODE, VP>), dim3((unsigned)(trips < cap ? (trips < 1 ? 1 : trips) : cap)), dim3(256),
+                       lds, st, rp, ci, v, xin, ldx, y, ldy, (int)n, ev, OUT, ld_row, F);
+}
+
 template <int MODE>
 static int launch_csr_step(int C, int G, const int *rp, const int *ci, const float *v, const float *xin, int ldx,
                            float *y, int ldy, int64_t n, const StepEv &ev, float *OUT, int64_t ld_row, int F, hipStream_t st,
                            int planes = 1)
 {
+    // one value per entry: staged (cfg2-shaped single product 0.123 -> 0.102 ms).  The per-channel formats keep the
+    // lane-group kernel, whose four-entries-per-lane batching is faster for them (cfg3 factored chain 8.3 vs 9.3 ms staged).
+    if (planes != 3 && planes != 4 && !step_lanes("ESCAT_CSR_STEP")) {
+        switch (C) {
+#define CASE(c) case c: launch_csr_step_staged<c, MODE, 1>(rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F, st); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+            default: return fail(ESCAT_ERANGE, "C=%d outside [1,%d]", C, ESCAT_MAX_CHANNELS);
+        }
+        return ESCAT_OK;
+    }
     if (planes == 3 || planes == 4) {
         if (C != 3) return fail(ESCAT_EINVAL, "one value per channel (val_planes = 3, 4) needs C = 3, got %d", C);
 #define GO(GG, VV, RPB) hipLaunchKernelGGL((k_csr_step<3, GG, MODE, VV>), dim3(grid_for(n, RPB)), dim3(256), 0, st, rp, ci, v, xin, ldx, y, ldy, n, ev, OUT, ld_row, F)
@@ -832,17 +975,11 @@ static int launch_csr_step(int C, int G, const int *rp, const int *ci, const flo
     return ESCAT_OK;
 }
 
-static bool bsr3_step_lanes()          // ESCAT_BSR3_STEP=lanes: the round-1 lane-group kernel (debug aid, tests)
-{
-    const char *e = getenv("ESCAT_BSR3_STEP");          // read per launch: tests switch it inside one process
-    return e && !strcmp(e, "lanes");
-}
-
 template <int MODE>
 static void launch_bsr3_step(int g, const int *rp, const int *ci, const float *blk, const float *xin, float *y,
                              int64_t nb, int64_t nnzb, const StepEv &ev, float *OUT, int F, hipStream_t st)
 {
-    if (!bsr3_step_lanes()) {
+    if (!step_lanes("ESCAT_BSR3_STEP")) {
         // static trip order: every workgroup of the grid must be resident, so the grid is what the device holds
         static const int per_cu = [] {
             int occ = 0;

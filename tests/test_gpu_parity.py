@@ -227,7 +227,8 @@ def test_all_three_chain_paths_agree(monkeypatch):
     opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
     opQ = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
     assert opP.csr().max_part_rows == 300 and opQ.bsr3().max_row_nnz >= 11
-    monkeypatch.setenv("ESCAT_BSR3_STEP", "lanes")     # the lane-group step kernel (the staged one: test_gpu_round2.py)
+    monkeypatch.setenv("ESCAT_BSR3_STEP", "lanes")     # the lane-group step kernels (the staged ones: test_gpu_round2.py)
+    monkeypatch.setenv("ESCAT_CSR_STEP", "lanes")
     g = torch.Generator().manual_seed(1)
     x = torch.randn(b["N"], 3, generator=g)
     xv = torch.from_numpy(b["pos"]).reshape(-1, 1)

@@ -262,3 +262,58 @@ def test_bsr3_single_product_staged():
     ev = np.array([[1, 0, 1, -1]], dtype=np.int32)
     ref = co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], x.numpy(), ev, 1, 1).reshape(-1)
     assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("graphs,n,k,C", [(3, 1500, 6, 3), (2, 1100, 40, 3), (2, 1300, 9, 1), (2, 1300, 9, 5), (1, 2000, 30, 8), (1, 37, 5, 2)])
+def test_csr_step_staged_vs_oracle(monkeypatch, graphs, n, k, C):
+    """Multi-launch scalar chain through the LDS-staged step kernel (k_csr_step_staged, the default) and through the
+    round-1 lane-group kernel (ESCAT_CSR_STEP=lanes): forward and x.grad against the C oracle, every channel count's
+    trip shape (64 rows for C <= 4, 32 beyond), and trips beyond the LDS capacity (k = 30, 40: straight from global)."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(graphs, n, k, seed=17)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rows_per_trip = 64 if C <= 4 else 32
+    if k >= 30:
+        assert np.diff(b["rowptr"][::rows_per_trip]).max() > rows_per_trip * 24
+    op = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    kw = dict(J=3)
+    plan = plan_chain(**kw)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(b["N"], C, generator=gen)
+    g = torch.randn(b["N"], C, plan.F, generator=gen)
+    ref = co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F)
+    refg = co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], g.numpy(), ev, plan.T)
+    monkeypatch.setenv("ESCAT_CHAIN_PATH", "multi")
+    outs = []
+    for step in (None, "lanes"):
+        if step:
+            monkeypatch.setenv("ESCAT_CSR_STEP", step)
+        xg = x.to(dev).requires_grad_(True)
+        W = get_Batch_Wjxs(xg, op, **kw)
+        W.backward(g.to(dev))
+        for got, want in ((W, ref), (xg.grad, refg)):
+            got = got.detach().cpu().numpy().reshape(want.shape)
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()       # north_star's bar
+        outs.append(W.detach())
+    assert (outs[0] - outs[1]).abs().max() <= 2e-6 * outs[1].abs().max()
+
+
+def test_csr_single_product_staged_strided():
+    """escat_csr_spmm_f32 (one torch.sparse.mm(P, X)) through the staged kernel with leading dimensions larger than C."""
+    from esc_gnn_amd import synthetic, _lib
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(7, 200, 7, seed=6)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    rp, ci, pv = t(b["rowptr"]), t(b["col"]), t(b["pval"])
+    N = b["N"]
+    X = torch.randn(N, 6, device=dev)
+    Y = torch.full((N, 5), 7.0, device=dev)
+    rc = _lib.load().escat_csr_spmm_f32(rp.data_ptr(), ci.data_ptr(), pv.data_ptr(), N, b["nnz"], X.data_ptr(), 6, Y.data_ptr(), 5, 4,
+                                        torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    rows = np.repeat(np.arange(N), np.diff(b["rowptr"]))
+    P = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, b["col"]])).long(), torch.from_numpy(b["pval"]), (N, N))
+    ref = torch.sparse.mm(P, X.cpu()[:, :4])
+    assert (Y.cpu()[:, :4] - ref).abs().max() <= 1e-5 * ref.abs().max() and bool((Y[:, 4] == 7.0).all())
