@@ -505,7 +505,7 @@ __device__ __forceinline__ void chain_epilogue_orders(const float *slab, float *
 //   LDS: xa | xb (two copies each) | slab | inb   -- inb = staged x (fwd) or the second slab (bwd, `early`);
 //   bwd without room for two slabs (`early` = 0) copies the next input in after the last step instead.
 template <class Op, int NT, bool BWD, bool ORD>     // ORD: forward with the orders epilogue (a separate instantiation:
-__global__ void __launch_bounds__(NT, Op::MINW)      // compiled into the plain kernel, its code costs the step loop registers)
+__global__ void __launch_bounds__(NT, (Op::MINW == 1 && NT == 256) ? 2 : Op::MINW)      // compiled into the plain kernel, its code costs the step loop registers)
 k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev sd, const float *__restrict__ IN,
              float *__restrict__ RES, int T, EvTable tab, int F, int n_parts, int max_rows, int early)
 {
@@ -682,7 +682,10 @@ static int launch_sell_k2(const int *ci, const float *v, int n_parts, int max_ro
                           float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
     int early = 0;
-    const int want = Op::MINW == 1 ? 1 : (NT == 512 ? 2 : 4);
+    // workgroups per CU the registers allow: the 256-VGPR BSR-3 kernel holds one of 512 threads or two of 256 (without
+    // the bound above the compiler takes up to 512 registers for a 256-thread kernel: DMAX >= 20 then ran ONE 4-wave
+    // workgroup per CU, 0.69 instead of 0.41 ms for 8192 graphs x 250 nodes)
+    const int want = Op::MINW == 1 ? (NT == 512 ? 1 : 2) : (NT == 512 ? 2 : 4);
     const size_t lds = escat_sell_lds_bytes(Op::C, Op::CP, max_rows, F, BWD, want, &early, sd.orders);
     if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "register-resident chain needs %zu B of LDS", lds);
     if (ORD) {
