@@ -279,7 +279,8 @@ extern "C" int escat_build_knn_P_grid(const float *pos, int64_t n_nodes, int k, 
     if (!pos || !rowptr || !col || !pval || !nnz_out) return fail(ESCAT_EINVAL, "NULL pointer");
     if (k < 1 || k > GRID_KMAX) return fail(ESCAT_ERANGE, "k=%d outside [1,%d]", k, GRID_KMAX);
     if (n_nodes < 1) return fail(ESCAT_EINVAL, "empty input");
-    if (n_nodes >= (int64_t)1 << 31 || n_nodes * k >= (int64_t)1 << 40) return fail(ESCAT_ERANGE, "n_nodes too large");
+    if (n_nodes * (2 * (int64_t)k + 1) >= (int64_t)1 << 31)      // the most nonzeros the symmetrised graph can have: int32 offsets
+        return fail(ESCAT_ERANGE, "n_nodes * (2k + 1) >= 2^31");
     const size_t need = escat_build_grid_workspace_bytes(n_nodes, k);
     if (!workspace || workspace_bytes < need) return fail(ESCAT_EWORKSPACE, "workspace %zu B < %zu B needed", workspace_bytes, need);
     if (cap < n_nodes) return fail(ESCAT_EINVAL, "cap smaller than the number of nodes");

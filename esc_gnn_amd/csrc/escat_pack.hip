@@ -409,6 +409,7 @@ k_transpose_sym(const int *__restrict__ rowptr, const int *__restrict__ col, con
     if (i >= n) return;
     for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
         const int j = col[e];
+        if (j < 0 || j >= n) { atomicOr(not_symmetric, 1); continue; }      // not a valid operator: let the caller find out
         int lo = rowptr[j], hi = rowptr[j + 1] - 1, at = -1;
         while (lo <= hi) {                         // rows are sorted by column
             const int mid = (lo + hi) >> 1, c = col[mid];
@@ -456,6 +457,8 @@ k_row_cover(const int *__restrict__ rowptr, const int *__restrict__ col, int64_t
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
     int lo = (int)r, hi = (int)r;
     if (e1 > e0) { const int a = col[e0], b = col[e1 - 1]; lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (lo < 0) lo = 0;                            // (columns outside [0, n): clamped here, rejected by the operator's validation)
+    if (hi >= n) hi = (int)n - 1;
     if (hi > lo) { atomicAdd(&delta[lo], 1); atomicAdd(&delta[hi], -1); }
 }
 
