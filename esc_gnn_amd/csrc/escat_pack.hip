@@ -206,6 +206,104 @@ k_pack_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const f
     for (int k = 0; k < w; ++k) {
         const bool padded = k >= cnt;
         const unsigned long long pm = __ballot(padded);
+        if constexpr (LAYOUT == 1) {
+            // Layout-1 packs: a MAXIMUM MATCHING of the lane group's 16 lanes onto the 16 bank slots instead of the
+            // greedy turn-taking below.  Every lane offers the slots its remaining entries can reach (two per entry: copy
+            // A and copy B); augmenting paths (Kuhn) give every lane a slot of its own whenever that is possible at all
+            // -- simulated multiplicity 1.02 against the greedy's 1.5-1.6.  All 16 lanes of a group run the same
+            // search redundantly on nibble-packed registers (no LDS, no divergence between the groups of a wave).
+            unsigned mycand = 0;
+            if (!padded) {
+                unsigned m = rem;
+                while (m) {
+                    const int j = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int a = cols[lane][j];
+                    mycand |= 1u << (a & 15);
+                    mycand |= 1u << (sell_swzB(a) & 15);       // (R is a multiple of 16: the slot of R + swzB(a))
+                }
+            }
+            constexpr int idx0[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+            constexpr int idx1[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+            unsigned long long cw[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+            unsigned active = 0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const unsigned ct = (unsigned)__shfl((int)mycand, (lane & 32) + (g0 ? idx0[t] : idx1[t]), 64);
+                cw[t >> 2] |= (unsigned long long)ct << (16 * (t & 3));
+                if (ct) active |= 1u << t;
+            }
+            auto cand_of = [&](int x) -> unsigned {
+                const unsigned long long v = x < 8 ? (x < 4 ? cw[0] : cw[1]) : (x < 12 ? cw[2] : cw[3]);
+                return (unsigned)(v >> (16 * (x & 3))) & 0xffffu;
+            };
+            auto nget = [](unsigned long long v, int i) -> int { return (int)((v >> (4 * i)) & 15ULL); };
+            auto nset = [](unsigned long long &v, int i, int x) { v = (v & ~(15ULL << (4 * i))) | ((unsigned long long)x << (4 * i)); };
+            const unsigned dummy = (pm & gmask) ? (1u << zslot) : 0u;     // padded lanes read the zero row (copy A)
+            unsigned occupied = dummy, mmatched = 0;
+            unsigned long long bin_member = 0ULL, member_bin = 0ULL;
+            for (int u = 0; u < 16; ++u) {
+                if (!((active >> u) & 1u)) continue;
+                unsigned visited = dummy;
+                unsigned long long prev = 0ULL, queue = (unsigned long long)u;
+                int qh = 0, qt = 1, found = -1;
+                while (qh < qt && found < 0) {
+                    const int x = nget(queue, qh); ++qh;
+                    unsigned m = cand_of(x) & ~visited;
+                    const unsigned f = m & ~occupied;
+                    if (f) { found = __ffs(f) - 1; nset(prev, found, x); break; }
+                    while (m) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        visited |= 1u << b;
+                        nset(prev, b, x);
+                        if (qt < 16) { nset(queue, qt, nget(bin_member, b)); ++qt; }
+                    }
+                }
+                if (found >= 0) {
+                    int b = found;
+                    for (int guard = 0; guard < 17; ++guard) {
+                        const int x = nget(prev, b);
+                        const bool had = (mmatched >> x) & 1u;
+                        const int nb = nget(member_bin, x);
+                        nset(bin_member, b, x); occupied |= 1u << b;
+                        nset(member_bin, x, b); mmatched |= 1u << x;
+                        if (x == u || !had) break;
+                        b = nb;
+                    }
+                }
+            }
+            // lanes the matching could not seat (fewer free slots than lanes): the least-loaded slot they can reach
+            unsigned long long loads = 0ULL;
+            for (int b = 0; b < 16; ++b) if ((occupied >> b) & 1u) loads |= 1ULL << (4 * b);
+            for (int u = 0; u < 16; ++u) {
+                if (!((active >> u) & 1u) || ((mmatched >> u) & 1u)) continue;
+                unsigned m = cand_of(u);
+                int best = 99, bb = 0;
+                while (m) { const int b = __ffs(m) - 1; m &= m - 1; const int c = nget(loads, b); if (c < best) { best = c; bb = b; } }
+                if (nget(loads, bb) < 15) loads += 1ULL << (4 * bb);
+                nset(member_bin, u, bb);
+            }
+            if (!padded) {
+                const int mybin = nget(member_bin, turn);
+                unsigned m = rem;
+                int bj = -1, bpos = 0;
+                while (m) {
+                    const int j = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int a = cols[lane][j];
+                    if ((a & 15) == mybin) { bj = j; bpos = a; break; }
+                    const int b = R + sell_swzB(a);
+                    if ((b & 15) == mybin) { bj = j; bpos = b; break; }
+                }
+                if (bj < 0) { bj = __ffs(rem) - 1; bpos = cols[lane][bj]; }      // (cannot happen: mybin came from mycand)
+                ent_of_slot[lane][k] = (signed char)bj;
+                row_of_slot[lane][k] = (unsigned short)bpos;
+                if (slot_of_e) { slot_of_e[e0 + bj] = k; lc_of_e[e0 + bj] = bpos; }
+                rem &= ~(1u << bj);
+            }
+            continue;
+        }
         if (turn == 0) load[g] = (pm & gmask) ? (1ULL << (4 * zslot)) : 0ULL;
         for (int t = 0; t < 16; ++t) {
             if (turn == t && !padded) {
