@@ -1119,7 +1119,10 @@ size_t escat_sell_lds_bytes(int C, int CP, int max_rows, int F, bool bwd, int wa
     const size_t nv = (size_t)2 * sell_padR(max_rows) * CP;
     const size_t slab = ((size_t)max_rows * C * (F + (!bwd && orders ? 1 : 0)) + 3) & ~(size_t)3;
     const size_t base = (2 * nv + slab) * sizeof(float);
-    if (!bwd) { *early = 1; return base + ((((size_t)max_rows * C + 3) & ~(size_t)3)) * sizeof(float); }
+    if (!bwd) {                                   // + the staged input + the row -> position table of layout-1 packs
+        *early = 1;
+        return base + ((((size_t)max_rows * C + 3) & ~(size_t)3)) * sizeof(float) + (((size_t)max_rows + 3) & ~(size_t)3) * sizeof(int);
+    }
     const size_t two = base + slab * sizeof(float);
     if (two * want <= LDS_BUDGET) { *early = 1; return two; }
     *early = 0;

@@ -389,24 +389,30 @@ __device__ __forceinline__ int chain_prologue(float *xa, float *xb, float *slab,
 
 // the same for layout-1 packs: every owner builds its own row of the first vector (at its position xr, copy B at rB) from
 // the staged input, which is in the operator's row order (row r)
+// Forward: the slab row of a node is its POSITION too (posL[r] = position of row r, for the epilogue): the lanes of a
+// wave then touch the slab at a constant stride instead of at the sorted rows' scattered offsets (the events' LDS bank
+// conflicts were 16 % of the P chain's LDS cycles).
 template <bool BWD, int NT>
 __device__ __forceinline__ int chain_prologue_pos(float *xa, float *xb, float *slab, const float *inb, int rows, bool own, int r,
-                                                  int xr, int rB, int C, int CP, int F, int T, const EvTable &tab, int Fs, int so)
+                                                  int xr, int rB, int C, int CP, int F, int T, const EvTable &tab, int Fs, int so,
+                                                  int *posL = nullptr)
 {
     const int tid = threadIdx.x;
     int p;
     if (tid < CP) { xa[rows * CP + tid] = 0.f; xb[rows * CP + tid] = 0.f; }
     if (!BWD) {
         int p1 = 0; while (p1 < tab.n && tab.e[p1].step == 0) ++p1;
-        if (own)
+        if (own) {
+            posL[r] = xr;
             for (int c = 0; c < C; ++c) {
-                const int i = r * C + c; const float y = inb[i];
+                const int i = xr * C + c; const float y = inb[r * C + c];
                 xa[xr * CP + c] = y;
                 xa[rB * CP + c] = y;
                 if (so) slab[i * Fs] = y;
                 for (int k = 0; k < p1; ++k)
                     if (tab.e[k].chan < 0 || tab.e[k].chan == c) emit_one(slab + i * Fs + so, y, tab.e[k].slot, tab.e[k].sign);
             }
+        }
         p = p1;
     } else {
         int p0 = tab.n; while (p0 > 0 && tab.e[p0 - 1].step == T) --p0;
@@ -450,13 +456,23 @@ __device__ __forceinline__ void rotate_rows(float *buf, const float *__restrict_
 
 template <bool BWD, int NT>
 __device__ __forceinline__ void chain_epilogue(const float *xa, const float *slab, float *__restrict__ RES, int64_t first_row,
-                                               int rows, int C, int CP, int F)
+                                               int rows, int C, int CP, int F, const int *posL = nullptr)
 {
     const int tid = threadIdx.x;
     const int nc = rows * C;
     if (!BWD) {
         float *og = RES + first_row * C * F;
-        for (int i = tid; i < nc * F; i += NT) og[i] = slab[i];
+        if (posL) {                               // slab rows are positions: output element (row, rest) <- slab[posL[row]]
+            const int cf = C * F;
+            int row = tid / cf, rest = tid % cf;
+            const int drow = NT / cf, drest = NT % cf;
+            for (int i = tid; i < nc * F; i += NT) {
+                og[i] = slab[posL[row] * cf + rest];
+                row += drow; rest += drest;
+                if (rest >= cf) { rest -= cf; ++row; }
+            }
+        } else
+            for (int i = tid; i < nc * F; i += NT) og[i] = slab[i];
     } else {
         float *dg = RES + first_row * C;
         for (int i = tid; i < nc; i += NT) dg[i] = xa[(i / C) * CP + i % C];
@@ -470,7 +486,7 @@ __device__ __forceinline__ void chain_epilogue(const float *xa, const float *sla
 // dead by now), then the tile goes out as a contiguous run; no per-element index arithmetic.
 template <int NT>
 __device__ __forceinline__ void chain_epilogue_orders(const float *slab, float *tile, int tile_floats, float *__restrict__ RES,
-                                                      int64_t first_row, int rows, int C, int F, int second)
+                                                      int64_t first_row, int rows, int C, int F, int second, const int *posL = nullptr)
 {
     const int wtot = 1 + F + (second ? F * (F - 1) / 2 : 0), Fs = F + 1;
     const int nrc = rows * C, per = tile_floats / wtot;
@@ -478,7 +494,8 @@ __device__ __forceinline__ void chain_epilogue_orders(const float *slab, float *
     for (int c0 = 0; c0 < nrc; c0 += per) {
         const int n = nrc - c0 < per ? nrc - c0 : per;
         for (int rc = threadIdx.x; rc < n; rc += NT) {
-            const float *srow = slab + (c0 + rc) * Fs;
+            const int rcg = c0 + rc;
+            const float *srow = slab + (posL ? posL[rcg / C] * C + rcg % C : rcg) * Fs;
             float *o = tile + rc * wtot;
             for (int f = 0; f <= F; ++f) o[f] = srow[f];
             if (second) {
@@ -519,6 +536,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
     float *inb = (BWD && !early) ? slab : slab + slab_sz;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int in_w = BWD ? C * F : C;                            // input floats per row
+    // layout 1, forward: slab rows are positions; posL (row -> position, written by the prologue) sits behind the staged input
+    int *posL = (POS && !BWD) ? reinterpret_cast<int *>(slab + slab_sz + ((max_rows * C + 3) & ~3)) : nullptr;
 
     int li = blockIdx.x;                          // index into the launch's list of parts
     if (li >= n_parts) return;
@@ -557,8 +576,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
                 __syncthreads();
             }
-            if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
-            else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+            if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);
+            else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F, posL);
         }
         STAMP(li, 2);
 
@@ -578,7 +597,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
             else rotate_rows<true, NT>(slab, sd.frames + (int64_t)gs * 9, rows, F, 3 * F, F);
             __syncthreads();
         }
-        int p = POS ? chain_prologue_pos<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, own, r, xr, rB, C, CP, F, T, tab, Fs, so)
+        const int srow = (POS && !BWD) ? xr : r;                          // this thread's slab row
+        int p = POS ? chain_prologue_pos<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, own, r, xr, rB, C, CP, F, T, tab, Fs, so, posL)
                     : chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab, Fs, so);
         if (POS && BWD && T == 0 && own)          // no step: the Horner start is the answer
             for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = xa[xr * CP + c];
@@ -610,7 +630,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 if (!BWD && own && pq1 > pq0) {
                     XVec<CP> yp; yp.load(xa + xr * CP);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) apply_events<false>(tab, pq0, pq1, c, yp.v[c], slab + (r * C + c) * Fs + so);
+                    for (int c = 0; c < C; ++c) apply_events<false>(tab, pq0, pq1, c, yp.v[c], slab + (srow * C + c) * Fs + so);
                 }
             });
 #ifdef ESCAT_STAMPS
@@ -623,7 +643,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 for (int c = 0; c < CP; ++c) y.v[c] = 0.f;
                 if (BWD) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) y.v[c] = apply_events<true>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
+                    for (int c = 0; c < C; ++c) y.v[c] = apply_events<true>(tab, q0, q1, c, acc[c], slab + (srow * C + c) * Fs + so);
                 } else {
 #pragma unroll
                     for (int c = 0; c < C; ++c) y.v[c] = acc[c];
@@ -635,7 +655,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 }
                 if (!BWD && (t == T || !DEFER)) { // the last step has no successor to hide behind
 #pragma unroll
-                    for (int c = 0; c < C; ++c) apply_events<false>(tab, q0, q1, c, acc[c], slab + (r * C + c) * Fs + so);
+                    for (int c = 0; c < C; ++c) apply_events<false>(tab, q0, q1, c, acc[c], slab + (srow * C + c) * Fs + so);
                 }
             }
             pq0 = q0; pq1 = (!BWD && DEFER && t < T) ? q1 : q0;
@@ -673,8 +693,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
         __syncthreads();
     }
-    if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2);
-    else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F);
+    if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);
+    else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F, posL);
 }
 
 template <class Op, int NT, bool BWD, bool ORD>
