@@ -91,6 +91,27 @@ def _knn_P_grid_batch(pos, gp, k, lib, dev):
     return torch.cat(rps).contiguous(), torch.cat(cols).contiguous(), torch.cat(vals).contiguous()
 
 
+def _knn_pattern(pos, graph_ptr, k):
+    """symmetrised kNN pattern (diagonal included) of a batch as CSR: the first third of build_PQ_batch."""
+    lib = _lib.load()
+    dev = pos.device
+    N, B = pos.shape[0], graph_ptr.numel() - 1
+    m = int((graph_ptr[1:] - graph_ptr[:-1]).max())
+    if m * ((m + 31) // 32) * 4 > 150 * 1024:
+        rowptr, col, _ = _knn_P_grid_batch(pos, graph_ptr.tolist(), k, lib, dev)
+        return rowptr, col
+    cap = N * (2 * k + 1)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(cap, dtype=torch.int32, device=dev)
+    pval = torch.empty(cap, dtype=torch.float32, device=dev)
+    nnz_d = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.escat_build_workspace_bytes(N, B, k) // 4, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.escat_build_knn_P(_ptr(pos), _ptr(graph_ptr), B, N, m, k, _ptr(rowptr), _ptr(col), _ptr(pval), cap,
+                                         _ptr(nnz_d), _ptr(ws), ws.numel() * 4, _stream(dev)), "escat_build_knn_P")
+    return rowptr, col[:int(nnz_d.item())]
+
+
 def build_PQ_batch(pos: torch.Tensor, graph_ptr: torch.Tensor, k: int, local_pca_kernel_fn_kwargs: Dict[str, Any],
                    use_mean_recentering: bool = False, enforce_sign: bool = True,
                    sing_vect_align_method: str = "column_dot", max_graph_nodes: Optional[int] = None,
@@ -230,10 +251,10 @@ def process_pyg_data(
             if k > 32:
                 raise NotImplementedError("escat: max_num_neighbors > 32 is beyond the kNN kernel")
             gp = torch.tensor([0, n], dtype=torch.int32, device=dev)
-            b = build_PQ_batch(v, gp, min(k, max(n - 1, 1)), {'kernel': 'gaussian'})   # pattern only; values redone below with weights
-            rp = b["rowptr"].long()
+            rp32, col32 = _knn_pattern(v, gp, min(k, max(n - 1, 1)))         # pattern only; values come below, with weights
+            rp = rp32.long()
             rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
-            cols = b["col"].long()
+            cols = col32.long()
             off = rows != cols
             edge_index = torch.stack([rows[off], cols[off]])        # symmetrised, row-major sorted: to_undirected's order
             if graph_construction == 'radius':
