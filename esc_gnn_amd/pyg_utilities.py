@@ -41,13 +41,14 @@ def _ptr(t: Optional[torch.Tensor]):
 
 def chain_lds_bytes(max_part_rows: int, C: int, F: int, bsr3: bool, backward: bool = False, orders: int = 0) -> int:
     """LDS a register-resident chain workgroup needs at least: two ping-pong vectors of two copies each, the output
-    slab, and (forward) the staged input.  (Backward adds a second slab when it fits -- decided in the library.)"""
+    slab, and (forward) the staged input and the row -> position table.  (Backward adds a second slab when it fits -- decided in the library.)"""
     from .operators import sell_pad_rows
     CP = 4 if bsr3 else (1 if C == 1 else 2 if C == 2 else 4 if C <= 4 else 8)
     cw = 3 if bsr3 else C
     slab = (max_part_rows * cw * (F + (1 if orders and not backward else 0)) + 3) & ~3
     stage = 0 if backward else (max_part_rows * cw + 3) & ~3
-    return (2 * 2 * sell_pad_rows(max_part_rows) * CP + slab + stage) * 4
+    pos = 0 if backward else (max_part_rows + 3) & ~3          # forward: the row -> position table (escat_sell_lds_bytes)
+    return (2 * 2 * sell_pad_rows(max_part_rows) * CP + slab + stage + pos) * 4
 
 
 class NoFusedOrders(Exception):

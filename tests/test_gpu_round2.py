@@ -317,3 +317,26 @@ def test_csr_single_product_staged_strided():
     P = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, b["col"]])).long(), torch.from_numpy(b["pval"]), (N, N))
     ref = torch.sparse.mm(P, X.cpu()[:, :4])
     assert (Y.cpu()[:, :4] - ref).abs().max() <= 1e-5 * ref.abs().max() and bool((Y[:, 4] == 7.0).all())
+
+
+def test_lds_budget_edge_falls_back_to_the_multi_launch_path():
+    """512-node graphs with 20 filters: the forward slab + vectors + staged input + row->position table need 164 864 B of
+    LDS, 1 KiB more than a CU has -- the Python side must see that (its size formula mirrors escat_sell_lds_bytes) and
+    take the multi-launch path instead of handing the library a launch it refuses; 19 filters still run register-resident."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain
+    from esc_gnn_amd.pyg_utilities import chain_lds_bytes, LDS_BUDGET
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(2, 512, 8, seed=12)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    op = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
+    assert op.csr().max_part_rows == 512
+    assert chain_lds_bytes(512, 3, 20, False) > LDS_BUDGET >= chain_lds_bytes(512, 3, 19, False)
+    x = torch.randn(b["N"], 3, generator=torch.Generator().manual_seed(4))
+    for nsc in (20, 19):
+        kw = dict(scales_type="custom", diffusion_scales=torch.arange(nsc))
+        plan = plan_chain(**kw)
+        assert plan.F == nsc
+        ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+        W = get_Batch_Wjxs(x.to(dev), op, **kw)
+        ref = co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F)
+        _close(W, ref)
