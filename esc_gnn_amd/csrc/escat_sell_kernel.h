@@ -454,7 +454,9 @@ __device__ __forceinline__ void rotate_rows(float *buf, const float *__restrict_
     }
 }
 
-template <bool BWD, int NT>
+// VEC2: copy two floats at a time in the permuted forward case (not for the BSR-3 kernel: at its 256-register limit the
+// second code path costs the step loop 4 spilled dwords)
+template <bool BWD, int NT, bool VEC2 = false>
 __device__ __forceinline__ void chain_epilogue(const float *xa, const float *slab, float *__restrict__ RES, int64_t first_row,
                                                int rows, int C, int CP, int F, const int *posL = nullptr)
 {
@@ -462,7 +464,17 @@ __device__ __forceinline__ void chain_epilogue(const float *xa, const float *sla
     const int nc = rows * C;
     if (!BWD) {
         float *og = RES + first_row * C * F;
-        if (posL) {                               // slab rows are positions: output element (row, rest) <- slab[posL[row]]
+        if (VEC2 && posL && ((C * F) & 1) == 0) { // the same two floats at a time (rows of an even number of floats)
+            const int cf = C * F, h = cf >> 1;
+            int row = tid / h, rest = tid % h;
+            const int drow = NT / h, drest = NT % h;
+            float2 *og2 = reinterpret_cast<float2 *>(og);
+            for (int i = tid; i < rows * h; i += NT) {
+                og2[i] = *reinterpret_cast<const float2 *>(slab + posL[row] * cf + 2 * rest);
+                row += drow; rest += drest;
+                if (rest >= h) { rest -= h; ++row; }
+            }
+        } else if (posL) {                        // slab rows are positions: output element (row, rest) <- slab[posL[row]]
             const int cf = C * F;
             int row = tid / cf, rest = tid % cf;
             const int drow = NT / cf, drest = NT % cf;
@@ -577,7 +589,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 __syncthreads();
             }
             if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);
-            else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F, posL);
+            else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT, Op::MINW != 1>(xa, slab, RES, prev_row0, prev_rows, C, CP, F, posL);
         }
         STAMP(li, 2);
 
@@ -694,7 +706,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         __syncthreads();
     }
     if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);
-    else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT>(xa, slab, RES, prev_row0, prev_rows, C, CP, F, posL);
+    else if (!(Op::POS && BWD)) chain_epilogue<BWD, NT, Op::MINW != 1>(xa, slab, RES, prev_row0, prev_rows, C, CP, F, posL);
 }
 
 template <class Op, int NT, bool BWD, bool ORD>
