@@ -146,7 +146,8 @@ typedef struct {
  *                          small results back (it synchronises `stream`) and fills *dims (host);
  *   escat_sell_pack_fill   with val_out (dims->val_floats floats, 16-byte aligned), lc_out (dims->lc_words words) and
  *                          lane_meta_out (n_slices*64*3 ints) allocated by the caller: one wave per slice plans slots and
- *                          vector copies (as escat_sell_plan_slots) and writes the slice.  The same workspace must be
+ *                          vector copies (layout 0: greedily, as escat_sell_plan_slots; layout 1: by a maximum matching
+ *                          of each ds_read_b128 lane group's 16 lanes onto the 16 bank slots) and writes the slice.  The same workspace must be
  *                          passed to both; afterwards it holds (int32) hist[64] | w[ns] | doff[ns+1] | poff[ns+1] |
  *                          perm[ns*64] | pos_of_row[n] with ns = n_slices, of which pos_of_row is what escat_sell wants.
  * values_per_entry: 1 (CSR), 9 (BSR-3 blocks, row-major), 3 (one value per channel); with sign_bits != NULL
