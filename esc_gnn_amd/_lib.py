@@ -31,7 +31,8 @@ class EscatSell(ctypes.Structure):
                 ("col32", ctypes.c_void_p), ("perm", ctypes.c_void_p), ("slice_doff", ctypes.c_void_p),
                 ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32),
                 ("orders", ctypes.c_int32), ("frames", ctypes.c_void_p),
-                ("layout", ctypes.c_int32), ("pos_of_row", ctypes.c_void_p)]
+                ("layout", ctypes.c_int32), ("pos_of_row", ctypes.c_void_p),
+                ("half_val", ctypes.c_void_p), ("half_aux", ctypes.c_void_p)]
 
 
 class EscatSellDims(ctypes.Structure):
@@ -59,6 +60,7 @@ SIGNATURES = {
     "escat_sell_pack_plan": (ci, [vp, i64, vp, ci, ci, ci, ci, vp, sz, vp, vp]),
     "escat_sell_pack_fill": (ci, [vp, vp, vp, vp, i64, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]),
     "escat_sell_pack_refill": (ci, [vp, vp, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp]),
+    "escat_sell_pack_refill_half": (ci, [vp, vp, i64, vp, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp]),
     "escat_ingest_coo": (ci, [vp, vp, i64, i64, ci, vp, vp, vp, vp]),
     "escat_row_cover": (ci, [vp, vp, i64, vp, vp]),
     "escat_merge_row_ranges": (i64, [vp, i64, i64, vp, vp]),

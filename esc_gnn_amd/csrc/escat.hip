@@ -33,15 +33,17 @@ int escat_fail(int code, const char *fmt, ...)      // shared with escat_build.h
     return code;
 }
 extern "C" const char *escat_last_error(void) { return g_err; }
-extern "C" int escat_abi_version(void) { return 2; }
+extern "C" int escat_abi_version(void) { return 3; }
 
 #ifdef ESCAT_STAMPS
 extern "C" int escat_debug_set_stamps_bsr3(void *), escat_debug_set_stamps_csr12(void *), escat_debug_set_stamps_csr34(void *),
-               escat_debug_set_stamps_csr56(void *), escat_debug_set_stamps_csr78(void *), escat_debug_set_stamps_csrv3(void *);
+               escat_debug_set_stamps_csr56(void *), escat_debug_set_stamps_csr78(void *), escat_debug_set_stamps_csrv3(void *),
+               escat_debug_set_stamps_bsr3h(void *);
 extern "C" int escat_debug_set_stamps(void *p)
 {
     return escat_debug_set_stamps_bsr3(p) | escat_debug_set_stamps_csr12(p) | escat_debug_set_stamps_csr34(p) |
-           escat_debug_set_stamps_csr56(p) | escat_debug_set_stamps_csr78(p) | escat_debug_set_stamps_csrv3(p);
+           escat_debug_set_stamps_csr56(p) | escat_debug_set_stamps_csr78(p) | escat_debug_set_stamps_csrv3(p) |
+           escat_debug_set_stamps_bsr3h(p);
 }
 #endif
 
@@ -1080,8 +1082,10 @@ static int chain_path_override()
 
 static int sell_to_dev(const escat_sell *sell, SellDev *sd)
 {
-    if (!sell->val || !sell->lc || !sell->lane_meta) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
+    if ((!sell->val && !sell->half_val) || !sell->lc || !sell->lane_meta) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
     if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
+    if ((sell->half_val != nullptr) != (sell->half_aux != nullptr)) return fail(ESCAT_EINVAL, "escat_sell.half_val and half_aux go together");
+    sd->half_val = sell->half_val; sd->half_aux = sell->half_aux;
     if (sell->slices_per_part != 4 && sell->slices_per_part != 8)
         return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d: must be 4 (parts <= 256 rows) or 8", sell->slices_per_part);
     if ((sell->part_list != nullptr) != (sell->part_row0 != nullptr) || (sell->part_list && sell->n_list < 0))
@@ -1271,6 +1275,12 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
             if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
+            // half-valued pack (escat_sell_bsr3h.hip) when given and instantiated for the capacity; ESCAT_Q_HALF=0: ignore it
+            static const bool no_half = getenv("ESCAT_Q_HALF") && !strcmp(getenv("ESCAT_Q_HALF"), "0");
+            if (sd.half_val && sd.dmax <= 20 && !(no_half && sd.val))
+                rc = escat_launch_bsr3h_sell(BWD, max_part_rows, col, blk, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
+            else if (!sd.val) return fail(ESCAT_EINVAL, "escat_sell.val is NULL and the half-valued pack cannot be used (dmax=%d)", sd.dmax);
+            else
             rc = escat_launch_bsr3_sell(BWD, max_part_rows, col, blk, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;
             CHECK_LAUNCH("k_chain_bsr3_sell");

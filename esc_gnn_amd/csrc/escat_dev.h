@@ -130,6 +130,7 @@ struct SellDev {
                                                   // global coordinates (the chain runs D Pt^t D^T instead of Pt^t)
     int layout;                                   // 0: LDS rows = local rows; 1: LDS rows = owner positions (see sell_swzB)
     const int *pos_of_row;                        // layout 1: global row -> position (for the streamed tails)
+    const void *half_val; const unsigned *half_aux;   // half-valued BSR-3 pack (escat_sell_bsr3h.hip), NULL otherwise
 };
 
 #define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
@@ -159,4 +160,5 @@ __attribute__((visibility("hidden"))) int escat_launch_csr_sell_c34(bool bwd, in
 __attribute__((visibility("hidden"))) int escat_launch_csr_sell_c56(bool bwd, int C, ESCAT_SELL_ARGS);
 __attribute__((visibility("hidden"))) int escat_launch_csr_sell_c78(bool bwd, int C, ESCAT_SELL_ARGS);
 __attribute__((visibility("hidden"))) int escat_launch_csrv3_sell(bool bwd, ESCAT_SELL_ARGS);
+__attribute__((visibility("hidden"))) int escat_launch_bsr3h_sell(bool bwd, ESCAT_SELL_ARGS);
 #endif

@@ -163,6 +163,54 @@ k_pack_refill(const int *__restrict__ rowptr, const float *__restrict__ val, con
     }
 }
 
+// the same for a BSR-3 operator whose values are all exactly representable as IEEE halves (escat_sell_bsr3h.hip): the
+// nine halves of a block as four pairs + b22 beside the slot's LDS offset.  *not_exact is raised by any value v with
+// float(half(v)) != v (NaNs included): the pack is then unusable and the caller keeps the fp32 pack.
+__device__ __forceinline__ unsigned half_bits_checked(float v, int &bad)
+{
+    const _Float16 h = (_Float16)v;
+    if (__float_as_uint((float)h) != __float_as_uint(v) || v != v) bad = 1;      // (a quiet NaN survives the round trip: refuse it by name)
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__global__ void __launch_bounds__(256)
+k_pack_refill_half(const int *__restrict__ rowptr, const float *__restrict__ val, const int *__restrict__ part_ptr,
+                   const int *__restrict__ perm, const int *__restrict__ doff_, const int *__restrict__ poff_,
+                   const signed char *__restrict__ ent, const unsigned *__restrict__ lc, int nsl, int n_slices,
+                   uint4 *__restrict__ hv_out, unsigned *__restrict__ aux_out, int *__restrict__ not_exact)
+{
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n_slices) return;
+    const int gs = part_ptr[s / nsl];
+    const int r = perm[(int64_t)s * 64 + lane];
+    const int doff = doff_[s], w = doff_[s + 1] - doff, poff = poff_[s];
+    const int64_t e0 = r >= 0 ? rowptr[gs + r] : 0;
+    int bad = 0;
+    for (int k0 = 0; k0 < w; k0 += 4) {
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = k0 + u < w ? (int)ent[(int64_t)(doff + k0 + u) * 64 + lane] : -1;
+        float b[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) get_values<9>(b[u], val, j[u] >= 0 ? e0 + j[u] : -1);
+        const unsigned l0 = lc[(int64_t)(poff + k0 / 2) * 64 + lane], l1 = lc[(int64_t)(poff + k0 / 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < w) {
+                unsigned hb[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) hb[q] = half_bits_checked(b[u][q], bad);
+                const unsigned row = ((u < 2 ? l0 : l1) >> ((u & 1) * 16)) & 0xffffu;
+                const int64_t o = (int64_t)(doff + k0 + u) * 64 + lane;
+                // pairs (b00 b10)(b01 b11)(b02 b12)(b20 b21), low | high << 16   (bij = b[3*i + j])
+                hv_out[o] = make_uint4(hb[0] | hb[3] << 16, hb[1] | hb[4] << 16, hb[2] | hb[5] << 16, hb[6] | hb[7] << 16);
+                aux_out[o] = hb[8] | (row * 16u) << 16;
+            }
+    }
+    if (bad) *not_exact = 1;
+}
+
 // ------------------------------------------------------------------ plan + fill, one wave per slice
 // V: floats per entry in `val` (1 scalar, 3 one per channel, 9 a 3x3 block); SIGNED (V == 3 input given as |value| +
 // sign bits): one plane of magnitudes, the three signs in bits 11..13 of the entry's 16-bit LDS-row field.
@@ -494,6 +542,31 @@ extern "C" int escat_sell_pack_refill(const int32_t *rowptr, const float *val, i
     else return fail(ESCAT_EINVAL, "values_per_entry=%d: 1, 3 or 9", values_per_entry);
 #undef GO
     CHECK_LAUNCH("escat_sell_pack_refill");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_sell_pack_refill_half(const int32_t *rowptr, const float *blk, int64_t n, const int32_t *part_ptr, int n_parts,
+                                           const escat_sell_dims *dims, const void *workspace, size_t workspace_bytes,
+                                           const int8_t *ent_of_slot, const uint32_t *lc, void *half_val_out,
+                                           uint32_t *half_aux_out, int32_t *not_exact, void *stream)
+{
+    if (!rowptr || !blk || !part_ptr || !dims || !workspace || !ent_of_slot || !lc || !half_val_out || !half_aux_out || !not_exact)
+        return fail(ESCAT_EINVAL, "NULL pointer");
+    if (((uintptr_t)half_val_out & 15) != 0) return fail(ESCAT_EINVAL, "half_val_out must be 16-byte aligned");
+    if (dims->layout != 1) return fail(ESCAT_EINVAL, "half-valued packs are layout 1");
+    const int64_t ns = dims->n_slices;
+    if (ns != (int64_t)n_parts * dims->slices_per_part) return fail(ESCAT_EINVAL, "dims do not belong to this operator");
+    if (workspace_bytes < pack_ws_ints(n, (int64_t)n_parts * 8) * sizeof(int)) return fail(ESCAT_EWORKSPACE, "workspace too small");
+    PackWs ws = pack_ws(const_cast<void *>(workspace), n, ns);
+    hipStream_t st = S(stream);
+    // the padding slot behind the last slice (empty slices read it)
+    hipError_t e = hipMemsetAsync((char *)half_val_out + dims->total_d * 64 * 16, 0, 64 * 16, st);
+    if (e == hipSuccess) e = hipMemsetAsync(half_aux_out + dims->total_d * 64, 0, 64 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_pack_refill_half, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st, rowptr, blk, part_ptr, ws.perm, ws.doff,
+                       ws.poff, (const signed char *)ent_of_slot, lc, dims->slices_per_part, (int)ns, (uint4 *)half_val_out,
+                       half_aux_out, not_exact);
+    CHECK_LAUNCH("escat_sell_pack_refill_half");
     return ESCAT_OK;
 }
 

@@ -192,6 +192,13 @@ def sell_swz_b(p):
 
 _PLAN_CACHE = {}         # (pattern identity, parts, dmax, layout) -> the last pack built on it (see Sell)
 
+# Half-valued BSR-3 packs (include/escat.h: escat_sell.half_val): "auto" -- when every block value is exactly
+# representable as an IEEE half (operators that went through the reference's fp16 HDF5 storage) the pack holds halves
+# and the chain runs escat_sell_bsr3h.hip, bit-identical to the fp32 pack's results; "0" -- never; "both" -- keep the
+# fp32 pack beside it (tests; the library then takes the half pack unless ESCAT_Q_HALF=0 is in ITS environment).
+HALF_MODE = os.environ.get("ESCAT_Q_HALF", "auto")
+HALF_MAX_DMAX = 20
+
 
 class Sell:
     """
@@ -236,13 +243,19 @@ class Sell:
                     break
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            self.half_val = self.half_aux = None
             if shared is not None:
                 dims = shared._dims
-                self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
-                _lib.check(lib.escat_sell_pack_refill(vp(form.rowptr), vp(form.val), n, vp(form.part_ptr), form.n_parts, V,
-                                                      ctypes.byref(dims), vp(shared._ws), shared._ws.numel() * 4,
-                                                      vp(shared._ent), vp(self.val), st), "escat_sell_pack_refill")
                 self.lc, self.lane_meta, ws, self._ent = shared.lc, shared.lane_meta, shared._ws, shared._ent
+                if V == 9:
+                    self._try_half(lib, form, dims, ws, st)
+                if self.half_val is None or HALF_MODE == "both":
+                    self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
+                    _lib.check(lib.escat_sell_pack_refill(vp(form.rowptr), vp(form.val), n, vp(form.part_ptr), form.n_parts, V,
+                                                          ctypes.byref(dims), vp(shared._ws), shared._ws.numel() * 4,
+                                                          vp(shared._ent), vp(self.val), st), "escat_sell_pack_refill")
+                else:
+                    self.val = None                      # the halves are the values: no fp32 copy of the pack
             else:
                 ws = torch.empty(lib.escat_sell_pack_workspace_bytes(n, form.n_parts) // 4, dtype=torch.int32, device=dev)
                 dims = _lib.EscatSellDims()
@@ -270,6 +283,8 @@ class Sell:
                                                     vp(self.lc_of_e) if keep_plan else null,
                                                     vp(self._ent) if self._ent is not None else null, st),
                            "escat_sell_pack_fill")
+                if V == 9 and self._ent is not None:
+                    self._try_half(lib, form, dims, ws, st)
         self._dims = dims
         self.dmax = int(dims.dmax)
         self.slices_per_part = int(dims.slices_per_part)
@@ -288,6 +303,23 @@ class Sell:
         if shared is None and self._ent is not None and layout is None:
             _PLAN_CACHE.clear()                          # one pattern at a time: batches come and go
             _PLAN_CACHE[key + (self.dmax,)] = self
+
+    def _try_half(self, lib, form, dims, ws, st):
+        """build the half-valued form of a BSR-3 pack on the plan at hand; keeps it iff every value is exact in fp16."""
+        import ctypes
+        from . import _lib
+        if HALF_MODE == "0" or self.layout != 1 or int(dims.dmax) > HALF_MAX_DMAX:
+            return
+        dev = form.rowptr.device
+        vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+        hv = torch.empty(((dims.total_d + 1) * 64, 4), dtype=torch.int32, device=dev)
+        ha = torch.empty((dims.total_d + 1) * 64, dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.escat_sell_pack_refill_half(vp(form.rowptr), vp(form.val), form.n, vp(form.part_ptr), form.n_parts,
+                                                   ctypes.byref(dims), vp(ws), ws.numel() * 4, vp(self._ent), vp(self.lc),
+                                                   vp(hv), vp(ha), vp(flag), st), "escat_sell_pack_refill_half")
+        if int(flag.item()) == 0:
+            self.half_val, self.half_aux = hv, ha
 
     @staticmethod
     def _capacity_for(V, cand) -> int:

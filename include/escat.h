@@ -137,6 +137,17 @@ typedef struct {
      * it).  escat_sell_pack_plan / _fill build either layout. */
     int32_t         layout;
     const int32_t  *pos_of_row;
+    /* ABI version 3, BSR-3 packs only, optional (NULL / NULL: none): the same pack with the block values held as IEEE
+     * halves, for an operator whose every value v satisfies float(half(v)) == v -- what the reference's ellipsoid pipeline
+     * stores (process_pyg_data.py:676 hdf5_tensor_dtype='float16'; widened at load, models/escgnn_data_classes.py:137-142).
+     *   half_val  uint32[(doff_s + d)*64 + lane][4] = half pairs, low | high << 16: (b00 b10) (b01 b11) (b02 b12) (b20 b21)
+     *   half_aux  uint32[(doff_s + d)*64 + lane]    = b22 (half) | (16 * LDS row of the slot) << 16
+     * (one padding slot behind the last slice, as for val).  escat_sell_pack_refill_half builds both and reports whether
+     * the values qualify.  The chain entry points then run a kernel that keeps a block in 5 registers instead of 9.5 (two
+     * workgroups per CU instead of one) and computes, in fp32, bit for bit what the fp32 pack gives.  dmax <= 20; val may be
+     * NULL when half_val is given (lc is not read either, but must be non-NULL). */
+    const void     *half_val;
+    const uint32_t *half_aux;
 } escat_sell;
 
 /* ---- the pack itself, built on the GPU (replaces round 1's torch index ops; esc_gnn_amd/operators.py::Sell calls
@@ -174,6 +185,16 @@ int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, const float 
 int escat_sell_pack_refill(const int32_t *rowptr, const float *val, int64_t n, const int32_t *part_ptr, int n_parts,
                            int values_per_entry, const escat_sell_dims *dims, const void *workspace,
                            size_t workspace_bytes, const int8_t *ent_of_slot, float *val_out, void *stream);
+
+/* The half-valued form of a BSR-3 pack (escat_sell.half_val / .half_aux) from the canonical blocks and the plan of a pack
+ * built before on the same pattern (workspace, ent_of_slot and lc of escat_sell_pack_fill, layout 1).  half_val_out:
+ * (dims->total_d + 1) * 64 * 16 bytes, 16-byte aligned; half_aux_out: (dims->total_d + 1) * 64 words.  *not_exact (device,
+ * caller zeroes) is set to 1 if some value is not exactly representable as an IEEE half (NaN included): the outputs are
+ * then meaningless and the caller keeps the fp32 pack. */
+int escat_sell_pack_refill_half(const int32_t *rowptr, const float *blk, int64_t n, const int32_t *part_ptr, int n_parts,
+                                const escat_sell_dims *dims, const void *workspace, size_t workspace_bytes,
+                                const int8_t *ent_of_slot, const uint32_t *lc, void *half_val_out, uint32_t *half_aux_out,
+                                int32_t *not_exact, void *stream);
 
 /* COO ingest of the two layouts the reference's pipeline produces (models/escgnn_data_classes.py:137-142: int64 COO,
  * flagged un-coalesced): blocks3 = 0: entries already row-major sorted and unique (P, process_pyg_data.py:775) ->

@@ -12,10 +12,14 @@ def main():
     ap.add_argument("--Jmax", type=int, default=4)
     ap.add_argument("--Jmin", type=int, default=0)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--half", action="store_true", help="round Q's blocks to fp16 first (half-valued pack, escat_sell_bsr3h.hip)")
     ap.add_argument("--gen-workers", type=int, default=min(16, os.cpu_count()))
     args = ap.parse_args()
     from esc_gnn_amd import synthetic
     b = synthetic.ellipsoid_batch(args.graphs, args.nodes, args.k, seed=457893, workers=args.gen_workers)
+    if args.half:
+        import numpy as np
+        b["blk"] = b["blk"].astype(np.float16).astype(np.float32)
     import torch
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain
     dev = torch.device("cuda:0")
@@ -25,7 +29,8 @@ def main():
     opP.csr_t(); opQ.bsr3_t()
     xs = t(b["pos"]).clone().requires_grad_(True)
     xv = t(b["pos"]).reshape(-1, 1).clone().requires_grad_(True)
-    res = {"max_row_nnz": opQ.bsr3().max_row_nnz, "nnz": b["nnz"], "N": b["N"], "path": os.environ.get("ESCAT_CHAIN_PATH", "auto")}
+    sq = opQ.bsr3().sell()
+    res = {"half_pack": sq.half_val is not None, "dmax": sq.dmax, "max_row_nnz": opQ.bsr3().max_row_nnz, "nnz": b["nnz"], "N": b["N"], "path": os.environ.get("ESCAT_CHAIN_PATH", "auto")}
     for J in range(args.Jmin, args.Jmax + 1):
         plan = plan_chain(J=J)
         for name, x, op in (("P", xs, opP), ("Q", xv, opQ)):

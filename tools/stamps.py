@@ -8,10 +8,14 @@ import numpy as np
 from esc_gnn_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libescat_stamps.so")
 from esc_gnn_amd import synthetic
+half = "--half" in sys.argv          # Q with fp16-exact blocks: the half-valued pack (escat_sell_bsr3h.hip)
+sys.argv = [a for a in sys.argv if a != "--half"]
 which = sys.argv[1] if len(sys.argv) > 1 else "Q"
 bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
 G = 4096
 b = synthetic.ellipsoid_batch(G, 500, 10, seed=457893, workers=8)
+if half:
+    b["blk"] = b["blk"].astype(np.float16).astype(np.float32)
 import torch
 from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator
 dev = torch.device("cuda:0")
@@ -44,6 +48,9 @@ for J in (0, 4):
     s = st.cpu().numpy().reshape(G, 16).astype(np.int64)
     names = ["operator loads issued", "previous epilogue issued", "input wait + barrier", "prologue", "step 1 (waits for the operator)",
              "steps 2..T", "post-step wait"]
+    if half:    # k_chain_qh: 0 part start, 1 lane records arrived, 2 input DMA + previous epilogue + operator loads issued, ...
+        names = ["lane records (HBM round trip)", "DMA + prev epilogue + op loads issued", "input wait + barrier", "prologue + operator wait",
+                 "step 1", "steps 2..T", "-"]
     print(f"== {which} {'bwd' if bwd else 'fwd'} J={J}: span {us(s[:, 6].max() - s[:, 0].min()):.1f} us")
     for k, nm in enumerate(names):
         a, bb = s[:, k], s[:, k + 1]
