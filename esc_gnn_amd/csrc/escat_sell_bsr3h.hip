@@ -24,6 +24,11 @@ __device__ __forceinline__ float fma_mix_lo(unsigned h, float x, float a)
 { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(a) : "v"(h), "v"(x)); return a; }
 __device__ __forceinline__ float fma_mix_hi(unsigned h, float x, float a)
 { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a) : "v"(h), "v"(x)); return a; }
+// fma(h, x, +0): the first term of an accumulator that starts at zero (no zero register to keep, no v_mov)
+__device__ __forceinline__ float mul_mix_lo(unsigned h, float x)
+{ float a; asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(a) : "v"(h), "v"(x)); return a; }
+__device__ __forceinline__ float mul_mix_hi(unsigned h, float x)
+{ float a; asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a) : "v"(h), "v"(x)); return a; }
 
 #ifndef ESCAT_QH_RING
 #define ESCAT_QH_RING 2
@@ -80,11 +85,17 @@ template <int DMAX> struct OpQH {
             else lds_wait<0>(xv[d % D]);
             const vf4 x = xv[d % D];
             // OpBsr3's order: (y0, y1) += (b0j, b1j) xj for j = 0, 1, 2; (t0, t1) += (b20 x0, b21 x1); u += b22 x2
-            s[0] = fma_mix_lo(h[d].x, x.x, s[0]); s[1] = fma_mix_hi(h[d].x, x.x, s[1]);
+            if (d == 0) {
+                s[0] = mul_mix_lo(h[d].x, x.x); s[1] = mul_mix_hi(h[d].x, x.x);
+                s[2] = mul_mix_lo(h[d].w, x.x); s[3] = mul_mix_hi(h[d].w, x.y);
+                s[4] = mul_mix_lo(m[d], x.z);
+            } else {
+                s[0] = fma_mix_lo(h[d].x, x.x, s[0]); s[1] = fma_mix_hi(h[d].x, x.x, s[1]);
+                s[2] = fma_mix_lo(h[d].w, x.x, s[2]); s[3] = fma_mix_hi(h[d].w, x.y, s[3]);
+                s[4] = fma_mix_lo(m[d], x.z, s[4]);
+            }
             s[0] = fma_mix_lo(h[d].y, x.y, s[0]); s[1] = fma_mix_hi(h[d].y, x.y, s[1]);
             s[0] = fma_mix_lo(h[d].z, x.z, s[0]); s[1] = fma_mix_hi(h[d].z, x.z, s[1]);
-            s[2] = fma_mix_lo(h[d].w, x.x, s[2]); s[3] = fma_mix_hi(h[d].w, x.y, s[3]);
-            s[4] = fma_mix_lo(m[d], x.z, s[4]);
             if (d + D < W) {
                 asm volatile("" :: "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]));     // see OpBsr3::gather_w
                 lds_gather(xv[d % D], addr(d + D));
@@ -123,30 +134,53 @@ k_chain_qh(const int *__restrict__ col, const float *__restrict__ blk, SellDev s
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int in_w = BWD ? C * F : C;
     const int xr = threadIdx.x;
+    // lane records of the NEXT part, fetched by LDS-DMA while this part runs (no registers held across the steps; every
+    // wave fetches and reads only its own slice's records, so no barrier is involved): metaR[tid] = row | tail_n << 10,
+    // metaS[wave * 8 + 0..4] = doff, poff, w, first row, rows
+    int *metaR = reinterpret_cast<int *>(BWD ? slab + slab_sz : reinterpret_cast<float *>(posL + ((max_rows + 3) & ~3)));
+    int *metaS = metaR + NT;
+    auto part_of = [&](int li_) { return sd.part_list ? sd.part_list[li_] : li_; };
+    auto dma_meta = [&](int part_) {
+        const int *lm = sd.lane_meta + ((int64_t)(part_ * sd.nsl + wave) * 64 + lane) * 3;
+        __builtin_amdgcn_global_load_lds((glb_void_t *)lm, (lds_void_t *)(metaR + wave * 64), 4, 0, 0);
+        if (lane < 8) __builtin_amdgcn_global_load_lds((glb_void_t *)(lm + 2), (lds_void_t *)(metaS + wave * 8), 4, 0, 0);
+    };
     int prev_row0 = 0, prev_rows = -1;
     OpQH<DMAX> op;
-    for (int li = blockIdx.x; li < n_parts; li += gridDim.x) {
-        const int part = sd.part_list ? sd.part_list[li] : li;
-        int row0 = sd.part_row0 ? sd.part_row0[li] : -1;
-        const int *lm = sd.lane_meta + ((int64_t)(part * sd.nsl + wave) * 64 + lane) * 3;
-        const int rt = lm[0], sw = lm[2];
+    int li = blockIdx.x;
+    if (li >= n_parts) return;
+    int part = part_of(li);
+    dma_meta(part);
+    bool x_staged = false;                        // forward: inb already holds this part's x (copied in during the previous part)
+    for (;;) {
+        STAMP(li, 0);
+        // this part's records -- and, forward, its x -- were requested a part ago (first part: just now)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int rt = metaR[threadIdx.x], sw = metaS[wave * 8 + (lane & 7)];
         const int doff = __builtin_amdgcn_readlane(sw, 0), w = __builtin_amdgcn_readlane(sw, 2);
         const int gs = __builtin_amdgcn_readlane(sw, 3), rows = __builtin_amdgcn_readlane(sw, 4);
-        if (row0 < 0) row0 = gs;
-#ifdef ESCAT_STAMPS
-        STAMP(li, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(li, 1);
-#endif
-        // input first (the slab of the previous part is dead: its last step ended with a barrier; inb since its prologue),
-        // then the previous result's stores, then the operator burst: the counted wait below leaves the burst in flight
-        dma_in<NT>(BWD ? slab : inb, IN + (int64_t)row0 * in_w, rows * in_w);
+        const int row0 = sd.part_row0 ? sd.part_row0[li] : gs;
+        const int liN = li + gridDim.x;
+        const bool has_next = liN < n_parts;      // uniform
+        const int partN = has_next ? part_of(liN) : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the records are in registers: their LDS words are free
+        STAMP(li, 1);
+        if (has_next) dma_meta(partN);
+        // backward (the slab of the previous part is dead: its last step ended with a barrier) and the first forward part:
+        // the input now, ahead of the operator burst, so that the counted wait below leaves the burst in flight
+        const bool stage_now = BWD || !x_staged;
+        if (stage_now) dma_in<NT>(BWD ? slab : inb, IN + (int64_t)row0 * in_w, rows * in_w);
+        asm volatile("" ::: "memory");
+        op.load(sd, doff, w, lane);
+        STAMP(li, 8);
+        if (stage_now) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(OpQH<DMAX>::NLOADS) : "memory");
+        STAMP(li, 9);
+        // the previous result leaves underneath the burst
         if (!BWD && prev_rows >= 0) {
             if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);
             else chain_epilogue<false, NT, true>(xa, slab, RES, prev_row0, prev_rows, C, CP, F, posL);
         }
-        asm volatile("" ::: "memory");
-        op.load(sd, doff, w, lane);
         STAMP(li, 2);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(OpQH<DMAX>::NLOADS) : "memory");
         const int r = (rt & 0x3ff) == 0x3ff ? -1 : (rt & 0x3ff);
         const bool own = r >= 0;
         const bool has_tail = __any((int)((unsigned)rt >> 10));  // wave-uniform, rare
@@ -158,6 +192,14 @@ k_chain_qh(const int *__restrict__ col, const float *__restrict__ blk, SellDev s
         if (BWD && T == 0 && own)
             for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = xa[xr * CP + c];
         op.point_odd_slot_at_zero_row(w, rows);
+        x_staged = false;
+        if (!BWD && has_next) {                   // the next part's x, now that its records are here and inb is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int swN = metaS[wave * 8 + (lane & 7)];
+            const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
+            dma_in<NT>(inb, IN + (int64_t)(sd.part_row0 ? sd.part_row0[liN] : gsN) * in_w, rowsN * in_w);
+            x_staged = true;
+        }
 #ifdef ESCAT_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(li, 4);
 #endif
@@ -200,6 +242,8 @@ k_chain_qh(const int *__restrict__ col, const float *__restrict__ blk, SellDev s
         }
         STAMP(li, 6); STAMP(li, 7);
         prev_row0 = row0; prev_rows = rows;
+        if (!has_next) break;
+        li = liN; part = partN;
     }
     if (!BWD && prev_rows >= 0) {
         if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);
@@ -213,7 +257,7 @@ static int launch_qh2(const int *ci, const float *v, int n_parts, int max_rows, 
 {
     int early = 0;
     // single-slab backward (`want` large enough that two slabs never "fit"): the second workgroup on the CU is the overlap
-    const size_t lds = escat_sell_lds_bytes(3, 4, max_rows, F, BWD, 1 << 20, &early, sd.orders);
+    const size_t lds = escat_sell_lds_bytes(3, 4, max_rows, F, BWD, 1 << 20, &early, sd.orders) + (NT + NT / 8) * sizeof(int);
     if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "register-resident chain needs %zu B of LDS", lds);
     if (ORD) {
         const int wtot = 1 + F + (sd.orders == 2 ? F * (F - 1) / 2 : 0);

@@ -199,6 +199,12 @@ _PLAN_CACHE = {}         # (pattern identity, parts, dmax, layout) -> the last p
 HALF_MODE = os.environ.get("ESCAT_Q_HALF", "auto")
 HALF_MAX_DMAX = 20
 
+# Factored form of a BSR-3 vector operator recovered from its blocks (escat_recover_factored, csrc/escat_factor.hip):
+# "auto" -- a BSR-3 operator whose blocks are p_ij G_i S_ij G_j^T to within FACTOR_TOL x max|Q| runs the vector chain in
+# the factored kernel (3 FMAs per entry instead of 9, two workgroups per CU); "0" -- never.
+FACTOR_MODE = os.environ.get("ESCAT_Q_FACTOR", "auto")
+FACTOR_TOL = 1e-6
+
 
 class Sell:
     """
@@ -449,6 +455,8 @@ class ScatterOperator:
         self.bsr_fill = 0.0
         self.row_perm = None            # set by _reorder_if_large: scalar rows, new -> old (x' = x[row_perm])
         self.row_inv = None             # old -> new (y = y'[row_inv])
+        self._factored = None           # see factored(): FactoredVectorOperator, or False once recovery was refused
+        self.factor_err = None          # relative reconstruction error of the recovery (diagnostic)
 
     def _parts_for(self, unit: int):
         """explicit parts for a form whose rows are `unit` scalar rows each (None: find the closed row ranges)"""
@@ -716,6 +724,46 @@ class ScatterOperator:
         if int(flag.item()):
             return None
         return _Csr(c.rowptr, c.col, val_t, c.n, (c.part_ptr, c.n_parts, c.max_part_rows))
+
+    def values_look_fp16(self) -> bool:
+        """a cheap probe (a few thousand values): were the blocks rounded to fp16 in storage?  Such an operator takes the
+        half-valued pack (checked in full when the pack is built), not the factored form (its blocks are no longer
+        p_ij x orthogonal)."""
+        b = self._bsr
+        if b is None or b.nnz == 0:
+            return False
+        v = b.val.reshape(-1)[:: max(1, b.val.numel() // 4096)]
+        return bool((v.to(torch.float16).to(torch.float32) == v).all())
+
+    def factored(self):
+        """Q = D Pt D^T recovered from the blocks (include/escat.h: escat_recover_factored): a FactoredVectorOperator that
+        reproduces every block to FACTOR_TOL x max|Q|, or None (fp16-rounded blocks, 'procrustes' alignment, parts too
+        large, FACTOR_MODE "0").  Tried once per operator."""
+        if self._factored is None:
+            self._factored = False
+            b = self._bsr
+            if b is not None and FACTOR_MODE != "0" and b.val.is_cuda and b.nnz > 0 and 0 < b.max_part_rows <= SELL_MAX_PART_ROWS \
+                    and self.row_perm is None and not self.values_look_fp16():
+                import ctypes
+                from . import _lib
+                lib = _lib.load()
+                dev = b.val.device
+                frames = torch.empty((b.n, 3, 3), dtype=torch.float32, device=dev)
+                val3 = torch.empty((b.nnz, 3), dtype=torch.float32, device=dev)
+                err = torch.zeros(1, dtype=torch.float32, device=dev)
+                vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+                with torch.cuda.device(dev):
+                    _lib.check(lib.escat_recover_factored(vp(b.rowptr), vp(b.col), vp(b.val), b.n, b.nnz, vp(b.part_ptr), b.n_parts,
+                                                          b.max_part_rows, vp(frames), vp(val3), vp(err),
+                                                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                               "escat_recover_factored")
+                scale = float(b.val.abs().max())
+                self.factor_err = float(err.item()) / scale if scale > 0 else float("inf")
+                if self.factor_err <= FACTOR_TOL:
+                    signed = ScatterOperator.from_csr(b.rowptr, b.col, val3, b.n, validate=False,
+                                                      parts=(b.part_ptr, b.n_parts, b.max_part_rows))
+                    self._factored = FactoredVectorOperator(frames, signed)
+        return self._factored or None
 
     def csr_t(self) -> _Csr:
         if self._csr_t is None:

@@ -223,8 +223,19 @@ def rotate_frames(frames: torch.Tensor, X: torch.Tensor, transpose: bool) -> tor
     return _RotateFrames.apply(frames, X, transpose)
 
 
+def vector_route(op, x, F: int):
+    """the operator the vector track (x of shape (3N, 1) on a BSR-3 operator) really runs on: the factored form recovered
+    from the blocks when the operator has one and its graphs fit the register-resident path, else the operator itself"""
+    if isinstance(op, ScatterOperator) and x.dim() == 2 and x.shape[1] == 1 and op.has_bsr3 and op.n == x.shape[0]:
+        f = op.factored()
+        if f is not None and f.fits_register_path(F):
+            return f
+    return op
+
+
 def bank(x: torch.Tensor, op, plan: ChainPlan) -> torch.Tensor:
     """(rows, C) -> (rows, C, F) for a chain plan on a canonical operator (differentiable w.r.t. x)."""
+    op = vector_route(op, x, plan.F)
     if isinstance(op, FactoredVectorOperator):
         if x.shape[1] != 1:
             raise ValueError("escat: the factored vector operator takes the flattened vector feature (3N, 1)")

@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .pyg_utilities import get_Batch_Wjxs, _ptr, _stream, _chain_launch, NoFusedOrders, MAX_C
+from .pyg_utilities import get_Batch_Wjxs, _ptr, _stream, _chain_launch, NoFusedOrders, MAX_C, vector_route
 from .operators import OperatorBatch, FactoredVectorOperator, as_operator
 from .scales import plan_chain
 
@@ -64,7 +64,7 @@ def _scatter_rows(x, P_or_Q, dkw, second_order):
         try:
             plan = plan_chain(scales_type=dkw.get('scales_type', 'dyadic'), diffusion_scales=dkw.get('diffusion_scales', None),
                               J=dkw.get('J', 5), include_lowpass=dkw.get('include_lowpass', True))
-            op = as_operator(P_or_Q)
+            op = vector_route(as_operator(P_or_Q), x, plan.F)
             if isinstance(op, FactoredVectorOperator):
                 # the kernel rotates [x | bank] back to global coordinates in LDS before it forms the products
                 if x.shape[1] == 1 and op.n == x.shape[0] and not plan.per_channel and op.fits_register_path(plan.F):

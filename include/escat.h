@@ -440,6 +440,19 @@ int escat_infogain_divergence_f32(const float *W, const int32_t *graph_ptr, int6
 int escat_rotate_frames_f32(const float *frames, const float *X, float *Y, int64_t n_nodes, int F, int transpose,
                             void *stream);
 
+/* The factored form of a BSR-3 vector operator recovered from its blocks alone (csrc/escat_factor.hip).  process_pyg_data
+ * builds Q_ij = p_ij O_i S_ij O_j^T, S_ij a diagonal sign matrix (process_pyg_data.py:306-313, :492), but hands the caller
+ * only the blocks (models/escgnn_modular.py:345-351; the frames are not in the HDF5 layout,
+ * generate_ellipsoid_dataset.py:1185-1206).  Per part (part_ptr: block rows, closed under the columns, <= 512 rows) this
+ * finds frames G (nb, 3, 3) and per-channel values val3 (nnzb, 3) = p_ij * diag(S_ij) such that Q_ij = p_ij G_i S_ij G_j^T:
+ * what escat_sell.frames + a val_planes = 3 / 4 operator take.  *max_err (device float, caller zeroes) receives the largest
+ * |p_ij G_i S_ij G_j^T - Q_ij| over all block entries: the caller accepts the factorisation iff that is within its
+ * tolerance (blocks rounded to fp16, the 'procrustes' alignment or any other operator leave it large). */
+size_t escat_recover_factored_lds_bytes(int max_part_rows);
+int escat_recover_factored(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
+                           const int32_t *part_ptr, int n_parts, int max_part_rows, float *frames_out, float *val3_out,
+                           float *max_err, void *stream);
+
 /* host utility (no GPU): Jenkins lookup3 "hashlittle", the checksum of HDF5 version-2 object headers
  * (esc_gnn_amd/hdf5_min.py, the writer of the reference's operator layout). */
 uint32_t escat_lookup3(const uint8_t *data, size_t n, uint32_t initval);

@@ -64,5 +64,8 @@ for J in (0, 4):
             print(f"   step 5, {nm:28s}: gather {g.mean():5.2f}  events+store {e.mean():5.2f}  barrier wait {bq.mean():5.2f} us")
         ok = (s[:, 8] > 0) & (s[:, 12] > 0)
         print(f"   step 5 start skew last-first wave: {us(s[ok, 12] - s[ok, 8]).mean():5.2f} us")
+    if half:
+        ok = (s[:, 8] > 0) & (s[:, 9] > 0)
+        print(f"   1 -> op loads issued {us(s[ok, 8] - s[ok, 1]).mean():6.2f} us; first-part input wait {us(s[ok, 9] - s[ok, 8]).mean():6.2f}; epilogue {us(s[ok, 2] - s[ok, 9]).mean():6.2f} us")
     ok = s[:, 7] > 0
     print(f"   part total (0 -> 7)                {us(s[ok, 7] - s[ok, 0]).mean():7.2f} us")
