@@ -15,8 +15,9 @@
 //   3. every other edge closes a cycle whose holonomy H_e = G_i^T R_ij G_j is, for a qualifying operator, a diagonal sign
 //      matrix seen in ONE unknown orthonormal basis (the root's true frame): the H_e are symmetric, orthogonal and commute.
 //      Their common eigenbasis V -- the eigenvectors of a sum of the H_e with pseudo-random weights (Jacobi) -- fixes the
-//      component's gauge: G_i <- G_i V.  (With G_root = I alone the check below fails wherever the sign field is not a
-//      pure gauge: 13-49 % of the edges of the builder goldens carry a -1.)
+//      component's gauge: G_i <- G_i V (with G_root = I alone the check below fails wherever the sign field is not a
+//      pure gauge: 13-49 % of the edges of the builder goldens carry a -1); two Newton steps of the joint
+//      diagonalisation, with the signs then known, sharpen V beyond what the eigenvalue gaps of the sum allow;
 //   4. two relaxation sweeps G_i <- polar(sum_j R_ij G_j S_ij) take the rounding drift of the tree walk out (the blocks
 //      are fp32: depth x 1e-7 of drift would otherwise show in the bank at the 1e-5 level);
 //   5. S_ij = sign diag(G_i^T R_ij G_j); the reconstruction error max |p_ij G_i S_ij G_j^T - Q_ij| over all blocks is
@@ -158,12 +159,16 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
         if (mine)
             for (int e = e0; e < e1; ++e) {
                 const int j = col[e] - gs;
-                if (j < 0 || j >= rows || state[j] < 0) continue;
+                if (j < 0 || j >= rows) continue;       // (a neighbour is in this component by definition)
                 double R[9], M[9], H[9];
                 if (!(load_R(blk, e, R) > 0.0)) continue;
                 mm(R, G + j * 9, M);
                 mtm(G + i * 9, M, H);
-                const double w = 0.5 + (double)(((unsigned)e * 2654435761u) >> 8) * (1.0 / 16777216.0);
+                // (a mixing hash: with a multiplicative one the DIFFERENCE of two weights depends on the difference of the entry
+                // indices only, and the regular patterns of small graphs made two eigenvalues of the sum coincide to 1e-7)
+                unsigned hsh = (unsigned)e;
+                hsh ^= hsh >> 16; hsh *= 0x85ebca6bu; hsh ^= hsh >> 13; hsh *= 0xc2b2ae35u; hsh ^= hsh >> 16;
+                const double w = 0.5 + (double)(hsh >> 8) * (1.0 / 16777216.0);
                 S6[0] += w * H[0]; S6[1] += w * 0.5 * (H[1] + H[3]); S6[2] += w * 0.5 * (H[2] + H[6]);
                 S6[3] += w * H[4]; S6[4] += w * 0.5 * (H[5] + H[7]); S6[5] += w * H[8];
             }
@@ -180,8 +185,50 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
             double Gi[9];
             mm(G + i * 9, s_V, Gi);
             for (int q = 0; q < 9; ++q) G[i * 9 + q] = Gi[q];
-            state[i] = -2;
         }
+        __syncthreads();
+        // The eigenvectors of the weighted sum are only as sharp as its eigenvalue gaps allow.  With the signs now known,
+        // two Newton steps of the joint diagonalisation proper: the rotation exp(W), W antisymmetric, that takes the
+        // off-diagonals of ALL holonomies out to first order, W_ab = -sum_e (d_a - d_b) H_e,ab / sum_e (d_a - d_b)^2.
+        for (int it = 0; it < 2; ++it) {
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            if (mine)
+                for (int e = e0; e < e1; ++e) {
+                    const int j = col[e] - gs;
+                    if (j < 0 || j >= rows) continue;
+                    double R[9], M[9], H[9];
+                    if (!(load_R(blk, e, R) > 0.0)) continue;
+                    mm(R, G + j * 9, M);
+                    mtm(G + i * 9, M, H);
+                    const double d0 = H[0] < 0.0 ? -1.0 : 1.0, d1 = H[4] < 0.0 ? -1.0 : 1.0, d2 = H[8] < 0.0 ? -1.0 : 1.0;
+                    acc[0] += (d0 - d1) * 0.5 * (H[1] + H[3]); acc[3] += (d0 - d1) * (d0 - d1);
+                    acc[1] += (d0 - d2) * 0.5 * (H[2] + H[6]); acc[4] += (d0 - d2) * (d0 - d2);
+                    acc[2] += (d1 - d2) * 0.5 * (H[5] + H[7]); acc[5] += (d1 - d2) * (d1 - d2);
+                }
+            for (int q = 0; q < 6; ++q) red[i * 6 + q] = acc[q];
+            __syncthreads();
+            for (int h = NT / 2; h >= 1; h >>= 1) {
+                if (i < h)
+                    for (int q = 0; q < 6; ++q) red[i * 6 + q] += red[(i + h) * 6 + q];
+                __syncthreads();
+            }
+            if (i == 0) {
+                const double w01 = red[3] > 0.0 ? -red[0] / red[3] : 0.0, w02 = red[4] > 0.0 ? -red[1] / red[4] : 0.0,
+                             w12 = red[5] > 0.0 ? -red[2] / red[5] : 0.0;
+                double U[9] = {1.0, w01, w02, -w01, 1.0, w12, -w02, -w12, 1.0};
+                if (!polar3(U))
+                    for (int q = 0; q < 9; ++q) U[q] = (q % 4 == 0) ? 1.0 : 0.0;
+                for (int q = 0; q < 9; ++q) s_V[q] = U[q];
+            }
+            __syncthreads();
+            if (mine) {
+                double Gi[9];
+                mm(G + i * 9, s_V, Gi);
+                for (int q = 0; q < 9; ++q) G[i * 9 + q] = Gi[q];
+            }
+            __syncthreads();
+        }
+        if (mine) state[i] = -2;
         __syncthreads();
     }
     // relaxation: every frame becomes the orthogonal factor closest to what its neighbours say it is

@@ -35,5 +35,11 @@ def bg():
 
 
 @pytest.fixture(scope="session")
+def r3g():
+    """round-3 goldens: the reference's vector track on a batch of column_dot graphs, fp32 and fp16-stored blocks"""
+    return np.load(os.path.join(GOLDEN, "round3_goldens.npz"))
+
+
+@pytest.fixture(scope="session")
 def ig():
     return np.load(os.path.join(GOLDEN, "infogain_goldens.npz"))

@@ -91,6 +91,34 @@ def test_f16_goldens_take_half_pack_and_match_fp32_kernel_bitwise(bg, oracle_lib
         _close(xh.grad.reshape(-1, 1), gref.reshape(-1, 1))
 
 
+def test_fp16_stored_operator_against_the_reference(r3g):
+    """goldens generated from the reference on the blocks as its ellipsoid pipeline stores and reloads them (fp16 -> fp32):
+    the drop-in takes the half-valued pack by itself and stays within 1e-5 of the reference's bank, x.grad and _scatter."""
+    from esc_gnn_amd import get_Batch_Wjxs, as_operator, scatter
+    dev = _dev()
+    n3 = int(r3g["N3"])
+    Q = torch.sparse_coo_tensor(torch.from_numpy(r3g["Q_indices"]).to(dev), torch.from_numpy(r3g["Q_values_f16"]).to(dev), (n3, n3))
+    xv = torch.from_numpy(r3g["x_v"]).to(dev)
+    op = as_operator(Q)
+    assert op.factored() is None and op.bsr3().sell().half_val is not None
+    modes = {"dyadic_J4": dict(scales_type="dyadic", J=4),
+             "custom_0_16": dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16])),
+             "custom_1_2_4": dict(scales_type="custom", diffusion_scales=torch.tensor([1, 2, 4])),
+             "dyadic_J2_nolp": dict(scales_type="dyadic", J=2, include_lowpass=False)}
+    for name, kw in modes.items():
+        x = xv.reshape(-1, 1).clone().requires_grad_(True)
+        W = get_Batch_Wjxs(x, Q, **kw)
+        _close(W, r3g[f"f16_{name}_W"])
+        W.backward(torch.from_numpy(r3g[f"f16_{name}_gup"]).to(dev))
+        _close(x.grad.reshape(-1, 1), r3g[f"f16_{name}_gx"].reshape(-1, 1))
+    kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=4, include_lowpass=True, diffusion_scales="dyadic")}
+    ref = r3g["f16_scatter_vector"]
+    for grad in (False, True):
+        S = scatter(track="vector", x0=xv.clone().requires_grad_(grad), P_or_Q=Q, kwargs=kw)
+        assert S.shape == ref.shape
+        _close(S.reshape(-1, S.shape[-1]), ref.reshape(-1, ref.shape[-1]), rtol=2e-5)   # products of two bands: 2 x 1e-5
+
+
 def test_non_exact_operator_keeps_fp32_pack(bg):
     """Q_values_f32 (not rounded): no half pack is kept; one inexact value among exact ones is enough."""
     from esc_gnn_amd import ScatterOperator

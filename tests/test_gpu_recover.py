@@ -1,0 +1,179 @@
+"""
+Round-3 GPU tests: the factored form of the vector operator recovered from the BSR-3 blocks alone
+(include/escat.h: escat_recover_factored, csrc/escat_factor.hip) and its automatic use by the drop-in.
+
+The reference hands get_Batch_Wjxs the COO of Q's blocks (models/escgnn_modular.py:345-351); its builder makes every block
+p_ij O_i S_ij O_j^T (data_processing/process_pyg_data.py:306-313, :492) but stores no frames.  For such an operator the
+ingest must find frames and signs by itself, verify them against the blocks, and run the factored kernel; for any other
+operator (fp16-rounded blocks, 'procrustes', random blocks) it must say no and keep BSR-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chain_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(a, ref, rtol=1e-5):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    for f in range(ref.shape[-1]):
+        d = np.abs(a[..., f] - ref[..., f]).max()
+        assert d <= rtol * np.abs(ref[..., f]).max() + 1e-30, (f, d, np.abs(ref[..., f]).max())
+
+
+def _coo(idx, val, n, dev):
+    return torch.sparse_coo_tensor(torch.from_numpy(idx.astype(np.int64)).to(dev), torch.from_numpy(val.astype(np.float32)).to(dev), (n, n))
+
+
+def _check_factors(op, f):
+    """frames orthonormal, the three channels differ in sign only, and p G S G^T gives the blocks back"""
+    b = op.bsr3()
+    G = f.frames.double()
+    eye = torch.eye(3, dtype=torch.float64, device=G.device)
+    assert float((G.transpose(1, 2) @ G - eye).abs().max()) < 1e-6
+    v3 = f.signed.csr().val
+    assert torch.equal(v3.abs(), v3[:, :1].abs().expand(-1, 3))
+    rp = b.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(b.n, device=G.device), rp[1:] - rp[:-1])
+    rec = torch.einsum("eac,ec,ebc->eab", G[rows], v3.double(), G[b.col.long()])
+    err = float((rec - b.val.double()).abs().max())
+    assert err <= 1.2e-6 * float(b.val.abs().max()), err
+
+
+def test_recovery_on_the_reference_builders_own_blocks(sg, bg, r3g):
+    """Q of the builder goldens g0-g4 (column_dot, with and without sign enforcement) and of their batch, fp32 as
+    process_pyg_data returns them: a factorisation is found and reproduces every block to 1e-6.  The round-1 scatter
+    goldens' batch contains the 'procrustes' graph g5: one graph without the structure refuses the whole operator."""
+    from esc_gnn_amd import ScatterOperator
+    dev = _dev()
+    n3 = int(sg["N"]) * 3
+    op = ScatterOperator.from_torch(_coo(sg["Q_indices"], sg["Q_values"], n3, dev))
+    assert op.factored() is None and op.factor_err > 1e-3
+    cases = [("batch", r3g["Q_indices"], r3g["Q_values_f32"], int(r3g["N3"]))]
+    for g in range(5):
+        cases.append((f"g{g}", bg[f"g{g}_Q_indices"], bg[f"g{g}_Q_values_f32"], int(bg[f"g{g}_Q_size"][0])))
+    for name, idx, val, n in cases:
+        op = ScatterOperator.from_torch(_coo(idx, val, n, dev))
+        f = op.factored()
+        assert f is not None, (name, op.factor_err)
+        assert op.factor_err <= 1e-6, (name, op.factor_err)
+        _check_factors(op, f)
+
+
+def test_drop_in_takes_the_factored_kernel_by_itself_and_matches_the_reference(r3g):
+    """get_Batch_Wjxs(x, Q_coo) and scatter(track='vector') on goldens generated from the reference (a batch of column_dot
+    graphs, fp32 blocks): the route is the factored operator found at ingest, and the bank, x.grad and the orders 0/1/2
+    stay within 1e-5 of what the reference's torch.sparse chain gave."""
+    from esc_gnn_amd import get_Batch_Wjxs, as_operator, scatter
+    from esc_gnn_amd.operators import FactoredVectorOperator
+    from esc_gnn_amd.pyg_utilities import vector_route
+    dev = _dev()
+    n3 = int(r3g["N3"])
+    Q = _coo(r3g["Q_indices"], r3g["Q_values_f32"], n3, dev)
+    xv = torch.from_numpy(r3g["x_v"]).to(dev)
+    assert isinstance(vector_route(as_operator(Q), xv.reshape(-1, 1), 6), FactoredVectorOperator)
+    modes = {"dyadic_J4": dict(scales_type="dyadic", J=4),
+             "custom_0_16": dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16])),
+             "custom_1_2_4": dict(scales_type="custom", diffusion_scales=torch.tensor([1, 2, 4])),
+             "dyadic_J2_nolp": dict(scales_type="dyadic", J=2, include_lowpass=False)}
+    for name, kw in modes.items():
+        x = xv.reshape(-1, 1).clone().requires_grad_(True)
+        W = get_Batch_Wjxs(x, Q, **kw)
+        _close(W, r3g[f"f32_{name}_W"])
+        W.backward(torch.from_numpy(r3g[f"f32_{name}_gup"]).to(dev))
+        _close(x.grad.reshape(-1, 1), r3g[f"f32_{name}_gx"].reshape(-1, 1))
+    kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=4, include_lowpass=True, diffusion_scales="dyadic")}
+    ref = r3g["f32_scatter_vector"]
+    for grad in (False, True):                      # fused orders (one launch) and bank + orders kernels
+        x0 = xv.clone().requires_grad_(grad)
+        S = scatter(track="vector", x0=x0, P_or_Q=Q, kwargs=kw)
+        assert S.shape == ref.shape
+        _close(S.reshape(-1, S.shape[-1]), ref.reshape(-1, ref.shape[-1]), rtol=2e-5)   # products of two bands: 2 x 1e-5
+
+
+def test_operators_without_the_structure_stay_bsr3(bg, monkeypatch):
+    """the 'procrustes' golden (g5: O_ij = (O_i O_j^T)^2), fp16-rounded blocks (even when the fp16 probe is bypassed) and
+    blocks with a random rotation per edge are refused; the chain then runs the BSR-3 kernels as before."""
+    from esc_gnn_amd import ScatterOperator, get_Batch_Wjxs, operators
+    from esc_gnn_amd.pyg_utilities import vector_route
+    dev = _dev()
+    n = int(bg["g5_Q_size"][0])
+    op = ScatterOperator.from_torch(_coo(bg["g5_Q_indices"], bg["g5_Q_values_f32"], n, dev))
+    assert op.factored() is None and op.factor_err > 1e-3
+    x = torch.randn(n, 1, device=dev)
+    assert vector_route(op, x, 6) is op
+    rowptr, col, blk = co.coo_to_bsr3(bg["g5_Q_indices"].astype(np.int64), bg["g5_Q_values_f32"].astype(np.float32), n)
+    ev = np.asarray(operators_plan_events(4), dtype=np.int32).reshape(-1, 4)
+    _close(get_Batch_Wjxs(x, op, J=4), co.c_chain_bsr3(rowptr, col, blk, x.cpu().numpy().reshape(-1), ev, 16, 6).reshape(n, 1, 6))
+    # fp16-rounded blocks: the probe routes them to the half pack; forced through the recovery they fail its check
+    n2 = int(bg["g2_Q_size"][0])
+    A16 = _coo(bg["g2_Q_indices"], bg["g2_Q_values_f16"].astype(np.float32), n2, dev)
+    op16 = ScatterOperator.from_torch(A16)
+    assert op16.values_look_fp16() and op16.factored() is None and op16.factor_err is None
+    monkeypatch.setattr(operators.ScatterOperator, "values_look_fp16", lambda self: False)
+    op16b = ScatterOperator.from_torch(_coo(bg["g2_Q_indices"], bg["g2_Q_values_f16"].astype(np.float32), n2, dev))
+    assert op16b.factored() is None and op16b.factor_err > 1e-4
+    # a random rotation per edge on P's pattern (what SURVEY 8d allows for pure throughput runs): not factorable
+    from esc_gnn_amd import synthetic
+    b = synthetic.ellipsoid_batch(4, 100, 5, seed=5)
+    R = synthetic.random_frames(b["nnz"], 99)
+    blk_r = (b["pval"][:, None, None] * R).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    opr = ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(blk_r), b["N"])
+    assert opr.factored() is None and opr.factor_err > 1e-2
+
+
+def operators_plan_events(J):
+    from esc_gnn_amd import plan_chain
+    return plan_chain(scales_type="dyadic", J=J).events
+
+
+@pytest.mark.parametrize("B,n,k", [(40, 500, 10), (64, 200, 5), (300, 7, 3), (6, 300, 12)])
+def test_recovered_form_against_the_bsr3_chain_and_the_oracle(oracle_lib, monkeypatch, B, n, k):
+    """builder-shaped blocks on synthetic batches (random frames, column-dot signs): 512- and 256-thread parts, parts made
+    of several tiny graphs (several connected components per workgroup): factored route = BSR-3 route = C oracle to 1e-5,
+    forward, backward and fused orders."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, synthetic, plan_chain, scatter, operators
+    from esc_gnn_amd.operators import FactoredVectorOperator
+    from esc_gnn_amd.pyg_utilities import vector_route
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(B, n, k, seed=2000 + n)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    mk = lambda: ScatterOperator.from_bsr3(t(b["rowptr"]), t(b["col"]), t(b["blk"]), b["N"])
+    op_f = mk()
+    f = op_f.factored()
+    assert f is not None and op_f.factor_err <= 1e-6, op_f.factor_err
+    _check_factors(op_f, f)
+    monkeypatch.setattr(operators, "FACTOR_MODE", "0")
+    op_b = mk()
+    assert op_b.factored() is None
+    monkeypatch.setattr(operators, "FACTOR_MODE", "auto")
+    xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
+    assert isinstance(vector_route(op_f, xv.to(dev), 6), FactoredVectorOperator)
+    kw = dict(scales_type="dyadic", J=4)
+    plan = plan_chain(**kw)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    xf, xb = xv.to(dev).requires_grad_(True), xv.to(dev).requires_grad_(True)
+    Wf, Wb = get_Batch_Wjxs(xf, op_f, **kw), get_Batch_Wjxs(xb, op_b, **kw)
+    ref = co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F).reshape(Wf.shape)
+    _close(Wf, ref)
+    _close(Wb, ref)
+    G = torch.randn(Wf.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    (Wf * G).sum().backward()
+    (Wb * G).sum().backward()
+    gref = co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], G.cpu().numpy().reshape(b["N"] * 3, -1), ev, plan.T)
+    _close(xf.grad.reshape(-1, 1), gref.reshape(-1, 1))
+    _close(xb.grad.reshape(-1, 1), gref.reshape(-1, 1))
+    pos = torch.from_numpy(b["pos"]).to(dev)
+    with torch.no_grad():
+        Sf = scatter(track="vector", x0=pos, P_or_Q=op_f, kwargs=dict(diffusion_kwargs=kw))
+        Sb = scatter(track="vector", x0=pos, P_or_Q=op_b, kwargs=dict(diffusion_kwargs=kw))
+    _close(Sf.reshape(-1, Sf.shape[-1]), Sb.cpu().numpy().reshape(-1, Sb.shape[-1]), rtol=2e-5)   # products of two bands: 2 x 1e-5
