@@ -260,7 +260,7 @@ template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
     static constexpr int MINW = 4;                // <= 128 VGPRs (60 of them values): two 512-thread workgroups per CU
     static constexpr int AHEAD = 2;               // gathers in flight (one fewer than OpCsr: the ring costs 4 VGPRs a stage)
     static constexpr bool FRAMES = true;          // SellDev.frames != NULL: rotate in and out of the local frames in LDS
-    static constexpr bool POS = false;            // layout-0 packs (LDS rows = local rows)
+    static constexpr bool POS = true;             // layout-1 packs (LDS rows = owner positions), as OpCsr / OpBsr3 (round 3)
     float v[DMAX][3];
     unsigned lc[DMAX / 2];
     __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)   // see OpBsr3::load
@@ -316,16 +316,17 @@ template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
     template <class Mid>
     __device__ __forceinline__ void gather(const float *xa, int w, float (&acc)[3], Mid mid) const { mid(); dispatch<2>((w + 1) >> 1, xa, acc); }
     static __device__ __forceinline__ void tail(const float *__restrict__ val, const int *__restrict__ col, int e0, int n,
-                                                int gs, const float *xa, float (&acc)[3], const int *__restrict__)
+                                                int gs, const float *xa, float (&acc)[3], const int *__restrict__ pos)
     {
         for (int e = e0; e < e0 + n; ++e) {
             if constexpr (SIGNED) {          // global arrays in the packed form of k_csr_step<.., 4>
                 const unsigned cw = (unsigned)col[e], vb = __float_as_uint(val[e]);
-                const float *x = xa + ((int)(cw & 0x1fffffffu) - gs) * 4;
+                const int cj = (int)(cw & 0x1fffffffu);
+                const float *x = xa + (pos ? pos[cj] : cj - gs) * 4;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[c] = fmaf(__uint_as_float(vb | ((cw << (2 - c)) & 0x80000000u)), x[c], acc[c]);
             } else {
-                const float *x = xa + (col[e] - gs) * 4;
+                const float *x = xa + (pos ? pos[col[e]] : col[e] - gs) * 4;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[c] = fmaf(val[(int64_t)e * 3 + c], x[c], acc[c]);
             }
@@ -432,13 +433,15 @@ __device__ __forceinline__ int chain_prologue_pos(float *xa, float *xb, float *s
 
 // in-place rotation of a part's 3-vectors in LDS by the rows' local frames (global, L1/L2-resident: 36 B per row):
 // buf[r * rs + c * cs + f] <- sum_c' O_r[c][c'] (TR: O_r[c'][c]) buf[r * rs + c' * cs + f]; rows are independent.
+// posL (layout 1, forward slab): the buffer's row of node r is its position posL[r]
 template <bool TR, int NT>
-__device__ __forceinline__ void rotate_rows(float *buf, const float *__restrict__ fr, int rows, int F, int rs, int cs)
+__device__ __forceinline__ void rotate_rows(float *buf, const float *__restrict__ fr, int rows, int F, int rs, int cs,
+                                            const int *posL = nullptr)
 {
     for (int r = threadIdx.x; r < rows; r += NT) {             // one thread per row: its frame is loaded once
         const float *o = fr + r * 9;
         const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4], o5 = o[5], o6 = o[6], o7 = o[7], o8 = o[8];
-        float *x = buf + r * rs;
+        float *x = buf + (posL ? posL[r] : r) * rs;
         for (int f = 0; f < F; ++f) {
             const float x0 = x[f], x1 = x[cs + f], x2 = x[2 * cs + f];
             if (TR) {
@@ -452,6 +455,15 @@ __device__ __forceinline__ void rotate_rows(float *buf, const float *__restrict_
             }
         }
     }
+}
+
+// one 3-vector out of its row's local frame (the arithmetic of rotate_rows<false>), in registers
+__device__ __forceinline__ void frame_to_global(float *v, const float *__restrict__ o)
+{
+    const float x0 = v[0], x1 = v[1], x2 = v[2];
+    v[0] = fmaf(o[2], x2, fmaf(o[1], x1, o[0] * x0));
+    v[1] = fmaf(o[5], x2, fmaf(o[4], x1, o[3] * x0));
+    v[2] = fmaf(o[8], x2, fmaf(o[7], x1, o[6] * x0));
 }
 
 // VEC2: copy two floats at a time in the permuted forward case (not for the BSR-3 kernel: at its 256-register limit the
@@ -584,8 +596,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         // ... and store the previous part's result underneath the stream
         if (prev_rows >= 0) {
             if constexpr (Op::FRAMES) if (sd.frames) {     // back to global coordinates (uniform branch)
-                if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs);   // ORD: [x | bank]
-                else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
+                if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs, posL);   // ORD: [x | bank]
+                else if (!POS) rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
                 __syncthreads();
             }
             if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);
@@ -612,8 +624,11 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         const int srow = (POS && !BWD) ? xr : r;                          // this thread's slab row
         int p = POS ? chain_prologue_pos<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, own, r, xr, rB, C, CP, F, T, tab, Fs, so, posL)
                     : chain_prologue<BWD, NT>(xa, xb, slab, BWD ? slab : inb, rows, R, C, CP, F, T, tab, Fs, so);
-        if (POS && BWD && T == 0 && own)          // no step: the Horner start is the answer
-            for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = xa[xr * CP + c];
+        if (POS && BWD && T == 0 && own) {        // no step: the Horner start is the answer
+            XVec<CP> y0; y0.load(xa + xr * CP);
+            if constexpr (Op::FRAMES) if (sd.frames) frame_to_global(y0.v, sd.frames + ((int64_t)gs + r) * 9);
+            for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = y0.v[c];
+        }
         STAMP(li, 4);
 
         int rtN = 0, te0N = 0, swN = 0;
@@ -662,6 +677,7 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
                 }
                 y.store(xb + xr * CP); y.store(xb + rB * CP);      // whole padded rows: one wide store per copy
                 if (POS && BWD && t == T) {       // layout 1: the owner holds the answer of its row -- straight to HBM
+                    if constexpr (Op::FRAMES) if (sd.frames) frame_to_global(y.v, sd.frames + ((int64_t)gs + r) * 9);   // (out of its local frame)
 #pragma unroll
                     for (int c = 0; c < C; ++c) RES[((int64_t)row0 + r) * C + c] = y.v[c];
                 }
@@ -701,8 +717,8 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         if (BWD && early) { float *tmp = slab; slab = inb; inb = tmp; }
     }
     if constexpr (Op::FRAMES) if (sd.frames) {
-        if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs);   // ORD: [x | bank]
-        else rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
+        if (!BWD) rotate_rows<false, NT>(slab, sd.frames + (int64_t)prev_gs * 9, prev_rows, Fs, 3 * Fs, Fs, posL);   // ORD: [x | bank]
+        else if (!POS) rotate_rows<false, NT>(xa, sd.frames + (int64_t)prev_gs * 9, prev_rows, 1, CP, 1);
         __syncthreads();
     }
     if (ORD) chain_epilogue_orders<NT>(slab, smem, 2 * nv, RES, prev_row0, prev_rows, C, F, sd.orders == 2, posL);

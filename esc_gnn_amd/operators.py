@@ -230,7 +230,7 @@ class Sell:
             raise ValueError("escat: per-channel CSR values must be (nnz, 3)")
         signed = form.signed_pack() if V == 3 else None
         self.val_planes = (4 if signed is not None else 3) if V == 3 else 1
-        self.layout = (0 if V == 3 else 1) if layout is None else int(layout)   # (override: tests of the pack itself)
+        self.layout = 1 if layout is None else int(layout)   # (override: tests of the pack itself; the kernels take layout 1)
         n, nnz = form.n, form.nnz
         if form.max_part_rows >= 0x3ff:
             raise ValueError("escat: part too large for the SELL lane record")

@@ -20,6 +20,7 @@ from .scales import ChainPlan, plan_chain
 
 LDS_BUDGET = 160 * 1024
 MAX_C = 8
+ESCAT_EVENT_ABS = 256          # include/escat.h
 
 
 @functools.lru_cache(maxsize=512)
@@ -223,19 +224,31 @@ def rotate_frames(frames: torch.Tensor, X: torch.Tensor, transpose: bool) -> tor
     return _RotateFrames.apply(frames, X, transpose)
 
 
-def vector_route(op, x, F: int):
+def vector_route(op, x, F: int, events=()):
     """the operator the vector track (x of shape (3N, 1) on a BSR-3 operator) really runs on: the factored form recovered
-    from the blocks when the operator has one and its graphs fit the register-resident path, else the operator itself"""
-    if isinstance(op, ScatterOperator) and x.dim() == 2 and x.shape[1] == 1 and op.has_bsr3 and op.n == x.shape[0]:
+    from the blocks when the operator has one and its graphs fit the register-resident path, else the operator itself.
+    Not when a chain path is forced (ESCAT_CHAIN_PATH: a diagnostic of the BSR-3 kernels), and not for a |.| bank (the
+    modulus must be taken in global coordinates; the factored kernel's slab is in the local frames)."""
+    if os.environ.get("ESCAT_CHAIN_PATH", "") or any(ev[2] not in (1, -1) for ev in events):     # (+-1 + ESCAT_EVENT_ABS)
+        return op
+    if not (x.dim() == 2 and x.shape[1] == 1 and op.n == x.shape[0]):
+        return op
+    if isinstance(op, ScatterOperator) and op.has_bsr3:
         f = op.factored()
         if f is not None and f.fits_register_path(F):
             return f
+    elif isinstance(op, OperatorBatch) and op.base.has_bsr3:
+        f = op.base.factored()
+        if f is not None and f.fits_register_path(F):
+            if getattr(op, "_factored_view", None) is None:
+                op._factored_view = f.select(op.part_ids)      # the same parts of the signed operator, the frames whole
+            return op._factored_view
     return op
 
 
 def bank(x: torch.Tensor, op, plan: ChainPlan) -> torch.Tensor:
     """(rows, C) -> (rows, C, F) for a chain plan on a canonical operator (differentiable w.r.t. x)."""
-    op = vector_route(op, x, plan.F)
+    op = vector_route(op, x, plan.F, plan.events)
     if isinstance(op, FactoredVectorOperator):
         if x.shape[1] != 1:
             raise ValueError("escat: the factored vector operator takes the flattened vector feature (3N, 1)")
@@ -247,9 +260,6 @@ def bank(x: torch.Tensor, op, plan: ChainPlan) -> torch.Tensor:
             return rotate_frames(op.frames, _WaveletBank.apply(u, op.signed, plan), transpose=False).view(x.shape[0], 1, -1)
         return _FactoredBank.apply(x.view(-1, 3), op, plan).view(x.shape[0], 1, -1)
     return _WaveletBank.apply(x, op, plan)
-
-
-ESCAT_EVENT_ABS = 256          # include/escat.h
 
 
 def abs_events(events):

@@ -64,7 +64,7 @@ def _scatter_rows(x, P_or_Q, dkw, second_order):
         try:
             plan = plan_chain(scales_type=dkw.get('scales_type', 'dyadic'), diffusion_scales=dkw.get('diffusion_scales', None),
                               J=dkw.get('J', 5), include_lowpass=dkw.get('include_lowpass', True))
-            op = vector_route(as_operator(P_or_Q), x, plan.F)
+            op = vector_route(as_operator(P_or_Q), x, plan.F, plan.events)
             if isinstance(op, FactoredVectorOperator):
                 # the kernel rotates [x | bank] back to global coordinates in LDS before it forms the products
                 if x.shape[1] == 1 and op.n == x.shape[0] and not plan.per_channel and op.fits_register_path(plan.F):
