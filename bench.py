@@ -24,8 +24,15 @@ Prints ONE JSON line (rank 0) with the contract's fields plus
                 duration inside the timed region, against 8 TB/s HBM peak.
   cpu_baseline  the CPU oracle's torch.sparse.mm restatement of the reference
                 (kind "port"), timed on a bounded sample of the same batch.
-  factored_Q_variant  (N = 1 only, after the timed region, NOT the headline) the same step with the vector operator
-                in factored form Q = D Pt D^T (esc_gnn_amd.FactoredVectorOperator).
+  route_Q       which kernel family the drop-in chose by itself for THIS Q (round 3): the blocks of the synthetic batch are
+                builder-shaped (p_ij O_i S_ij O_j^T in fp32, synthetic.q_blocks_from_frames = process_pyg_data.py:306-313,
+                :492), so the ingest recovers the factored form from the blocks (escat_recover_factored, verified to
+                1e-6 x max|Q|) and the vector chain runs the factored kernel.  `value` is that default behaviour.
+  variants      (N = 1 only, after the timed region) the same step on the same inputs with the routing forced:
+                "bsr3_fp32" = the BSR-3 register kernel (round 2's headline path: what an operator without the structure
+                gets), "fp16_stored_values" = the same blocks rounded to fp16 as the reference's ellipsoid pipeline
+                stores them (half-valued pack, bit-identical to bsr3 on those values), "factored_from_frames" = the
+                factored operator built from the true frames (the builder's own route).
 """
 import argparse
 import json
@@ -164,6 +171,51 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
                           "pattern_equal_to_host_kdtree": same}}
 
 
+def bench_fresh_coo(b, dev, t, args, xs, xv, reps=5):
+    """secondary, N = 1 only: the FUNCTION-level drop-in on what the reference's DataLoader hands over -- fresh torch sparse
+    COO tensors every step (int64 indices, flagged un-coalesced; P row-major sorted, Q in block-emission order:
+    models/escgnn_data_classes.py:137-142, process_pyg_data.py:839-857), forward only, both tracks, no gradient (how the
+    reference trains: the scattering sits outside the autograd graph).  COO in -> bank out, everything included: ingest,
+    parts, packs, routing, the two chains.  Under both ingest policies (esc_gnn_amd.operators.INGEST_POLICY)."""
+    import torch
+    from esc_gnn_amd import get_Batch_Wjxs, operators as _ops
+    N = b["N"]
+    rp = t(b["rowptr"]).long()
+    rows = torch.repeat_interleave(torch.arange(N, device=dev), rp[1:] - rp[:-1])
+    cols = t(b["col"]).long()
+    Pi = torch.stack([rows, cols]).contiguous()
+    a = torch.arange(3, device=dev)
+    Qi = torch.stack([((3 * rows)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1),
+                      ((3 * cols)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1)]).contiguous()
+    Pv, Qv = t(b["pval"]), t(b["blk"]).reshape(-1)
+    del rows, cols, rp
+    res = {}
+    for policy in ("full", "single_use"):
+        _ops.INGEST_POLICY = policy
+        ts = []
+        for r in range(reps + 1):
+            # a DataLoader's next batch has other graphs: nothing of the previous batch's plan or parts may be reused
+            # (here the pattern repeats, and the library would recognise it by content)
+            _ops._PLAN_CACHE.clear(); _ops._PARTS_CACHE.clear()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            P = torch.sparse_coo_tensor(Pi, Pv, (N, N), check_invariants=False)             # fresh tensor objects: no cache hit
+            Q = torch.sparse_coo_tensor(Qi, Qv, (3 * N, 3 * N), check_invariants=False)
+            with torch.no_grad():
+                Ws = get_Batch_Wjxs(xs, P, scales_type="dyadic", J=args.J)
+                Wv = get_Batch_Wjxs(xv, Q, scales_type="dyadic", J=args.J)
+            torch.cuda.synchronize()
+            if r >= 1:
+                ts.append((time.perf_counter() - t0) * 1e3)
+            del P, Q, Ws, Wv
+        ts.sort()
+        res[policy] = {"ms_per_step": ts[len(ts) // 2], "min_ms": ts[0], "max_ms": ts[-1]}
+    _ops.INGEST_POLICY = "full"
+    res["what"] = ("fresh int64 COO P and Q every step -> get_Batch_Wjxs forward for both tracks (no gradient), wall clock with a "
+                   "synchronise at both ends, median of %d; 'full' = default ingest (matching slot plan, factored form recovered "
+                   "from Q's blocks), 'single_use' = ESCAT_INGEST=single_use (unplanned packs, no recovery)" % reps)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +227,7 @@ def main():
     ap.add_argument("--J", type=int, default=4)
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fresh-coo", action="store_true", help="skip the function-level drop-in measurement on fresh COO tensors")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the secondary cfg3 measurement (one large cloud, N = 1 only)")
     ap.add_argument("--cfg3-nodes", type=int, default=2_000_000)
     ap.add_argument("--gen-workers", type=int, default=-1,
@@ -247,8 +300,13 @@ def main():
         torch.cuda.synchronize(); tc0 = time.perf_counter()
         p_ = ScatterOperator.from_csr(rowptr, col, pval_d, N)
         q_ = ScatterOperator.from_bsr3(rowptr, col, blk_d, N)
-        for form in (p_.csr(), p_.csr_t(), q_.bsr3(), q_.bsr3_t()):
+        for form in (p_.csr(), p_.csr_t()):
             form.sell()
+        qf = q_.factored()                   # round 3: the factored form recovered from the blocks, if they have one
+        if qf is not None and qf.fits_register_path(plan_chain(scales_type="dyadic", J=args.J).F):
+            qf.signed.csr().sell(); qf.signed.csr_t().sell()
+        else:
+            q_.bsr3().sell(); q_.bsr3_t().sell()
         torch.cuda.synchronize()
         return p_, q_, (time.perf_counter() - tc0) * 1e3
     _, _, canon_first_ms = canonicalise()          # includes loading the library's code objects and torch's first calls
@@ -275,13 +333,14 @@ def main():
     names = ("P_fwd", "Q_fwd", "P_bwd", "Q_bwd")
     evs = []
 
-    def step(record):
+    def step(record, opQ_=None, evs=evs):
+        opQ_ = opQ if opQ_ is None else opQ_
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
         xs.grad = None; xv.grad = None
         if record: e[0].record()
         Ws = get_Batch_Wjxs(xs, opP, scales_type="dyadic", J=args.J)
         if record: e[1].record()
-        Wv = get_Batch_Wjxs(xv, opQ, scales_type="dyadic", J=args.J)
+        Wv = get_Batch_Wjxs(xv, opQ_, scales_type="dyadic", J=args.J)
         if record: e[2].record()
         Ws.backward(gs)
         if record: e[3].record()
@@ -293,6 +352,19 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def variant(opQ_, note):
+        """the same step with another form of the vector operator (N = 1, after the timed region)"""
+        ev2 = []
+        for _ in range(args.warmup):
+            step(False, opQ_)
+        torch.cuda.synchronize(); tv0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True, opQ_, ev2)
+        torch.cuda.synchronize(); dtv = time.perf_counter() - tv0
+        perv = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in ev2) / len(ev2) for i, nm in enumerate(names)}
+        return {"value": args.graphs * args.steps / dtv, "unit": "graphs/s", "ms_per_step": dtv / args.steps * 1e3,
+                "kernels_ms": perv, "note": note}
 
     for _ in range(args.warmup):
         step(False)
@@ -320,14 +392,27 @@ def main():
         bytes_p = alg_bytes_scalar(N, nnz, C, T, F)
         alg_gbs = bytes_q / (per["Q_fwd"] * 1e-3) / 1e9
         comp_q = compulsory_bytes_vector(N, nnz, F)
-        traffic = measured_traffic(args, "k_chain_sell<OpBsr3", ", false, false>")
+        from esc_gnn_amd.operators import FactoredVectorOperator as _FVO
+        from esc_gnn_amd.pyg_utilities import vector_route
+        routed = vector_route(opQ, xv.detach(), F)
+        factored_route = isinstance(routed, _FVO)
+        half_route = (not factored_route) and opQ.bsr3().sell().half_val is not None
+        if factored_route:          # |p| + LDS row per nonzero, lane records, frames, x in, bank out
+            qkey, qname = "k_chain_sell<OpCsrV3", "k_chain_sell<OpCsrV3<..>, 512, false, false> (Q chain forward, factored form)"
+            comp_q = 6 * nnz + 12 * N + 36 * N + 12 * N + 12 * N * F
+        elif half_route:
+            qkey, qname = "k_chain_qh<", "k_chain_qh<.., 512, false, false> (Q chain forward, half-valued pack)"
+            comp_q = 20 * nnz + 12 * N + 12 * N + 12 * N * F
+        else:
+            qkey, qname = "k_chain_sell<OpBsr3", "k_chain_sell<OpBsr3<..>, 512, false, false> (Q chain forward)"
+        traffic = measured_traffic(args, qkey, ", false, false>")
         hbm_bytes = traffic if traffic is not None else comp_q
         achieved = hbm_bytes / (per["Q_fwd"] * 1e-3) / 1e9
         # LDS side of the same kernel: every step gathers 16 B per stored block and stores each node's new vector twice
         lds_bytes = T * (16 * nnz + 2 * 16 * N)
         lds_gbs = lds_bytes / (per["Q_fwd"] * 1e-3) / 1e9
         step_bytes = sum((measured_traffic(args, k, e) or 0) for k, e in
-                         (("k_chain_sell<OpBsr3", ", false, false>"), ("k_chain_sell<OpBsr3", ", true, false>"),
+                         ((qkey, ", false, false>"), (qkey, ", true, false>"),
                           ("k_chain_sell<OpCsr<3", ", false, false>"), ("k_chain_sell<OpCsr<3", ", true, false>")))
         out = {
             "metric": "graphs/sec for P+Q scattering fwd+bwd (J=4)",
@@ -342,7 +427,11 @@ def main():
                        "graphs_per_gpu": args.graphs, "nodes_per_graph": args.nodes, "k": args.k, "J": args.J,
                        "N": N, "nnz_P": nnz, "T": T, "F": F, "parallelism": f"dp{world} (graph shards, no data-path collective)"},
             "collective_backend": backend, "ranks_seen_by_allreduce": ranks_seen,
-            "roofline": {"bound": "hbm", "kernel": "k_chain_sell<OpBsr3<..>, 512, false, false> (Q chain forward)",
+            "route_Q": ("factored form recovered from the blocks at ingest (escat_recover_factored), relative reconstruction "
+                        f"error {opQ.factor_err:.2e}" if factored_route else
+                        "half-valued BSR-3 pack (every block value exact in fp16)" if half_route else
+                        "BSR-3 register kernel (fp32 pack)" + (f"; recovery refused, error {opQ.factor_err:.2e}" if opQ.factor_err is not None else "")),
+            "roofline": {"bound": "hbm", "kernel": qname,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "bytes_basis": "measured (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/hbm_traffic.json, same libescat.so)"
@@ -359,8 +448,10 @@ def main():
                                          "ds_read_b128 rate (MI355X_MICROARCH.md, LDS)"},
                          "regime": "the kernel keeps each graph's operator in registers for all T steps: HBM carries the "
                                    "operator once per chain (achieved/frac = those bytes / time vs the 8 TB/s peak); "
-                                   "algorithmic_GBs is SURVEY.md 8d's figure (operator re-streamed every step) for reference "
-                                   "only and is not a bandwidth."},
+                                   "algorithmic_GBs is SURVEY.md 8d's figure (BSR-3 operator re-streamed every step) for "
+                                   "reference only and is not a bandwidth: the kernels move far fewer bytes than that model "
+                                   "(registers instead of re-streaming; 6 B instead of 40 B per nonzero in the factored form), "
+                                   "so the time is bounded by LDS gathers and fp32 FMAs, not by HBM -- see roofline.lds and DESIGN.md 3."},
             "hbm_copy_measured_GBs": copy_gbs,
             "canonicalise_ms_once_per_batch": canon_ms,
             "canonicalise_ms_first_call_in_process": canon_first_ms,
@@ -370,27 +461,31 @@ def main():
                                 "Q_bwd": bytes_q / (per["Q_bwd"] * 1e-3) / 1e9},
         }
         if world == 1:
-            # secondary, NOT the headline: the same step with the vector operator in factored form (Q = D Pt D^T:
-            # frames + a signed scalar operator, esc_gnn_amd.FactoredVectorOperator) -- same inputs, same outputs to
-            # fp32 rounding (tests/test_gpu_factored.py), 12 B of operator values per nonzero instead of 36
-            from esc_gnn_amd import FactoredVectorOperator
+            # secondary, NOT the headline: the same step with the routing of the vector operator forced (same inputs)
+            from esc_gnn_amd import FactoredVectorOperator, operators as _ops
+            out["variants"] = {}
+            _ops.FACTOR_MODE = "0"
+            opQb = ScatterOperator.from_bsr3(rowptr, col, blk_d, N)
+            opQb.bsr3().sell(); opQb.bsr3_t().sell()
+            out["variants"]["bsr3_fp32"] = variant(opQb, "BSR-3 register kernel on the fp32 blocks (k_chain_sell<OpBsr3>): what an "
+                                                         "operator without the factored structure runs; round 2's headline path")
+            del opQb
+            blk16 = blk_d.to(torch.float16).to(torch.float32)
+            opQh = ScatterOperator.from_bsr3(rowptr, col, blk16, N)
+            opQh.bsr3().sell(); opQh.bsr3_t().sell()
+            assert opQh.bsr3().sell().half_val is not None
+            out["variants"]["fp16_stored_values"] = variant(opQh, "the same blocks rounded to fp16 as the reference's ellipsoid HDF5 stores "
+                                                                  "them (process_pyg_data.py:676): half-valued pack, k_chain_qh, two workgroups "
+                                                                  "per CU, bit-identical to the BSR-3 kernel on these values")
+            del opQh, blk16
+            _ops.FACTOR_MODE = "auto"
             opQf = FactoredVectorOperator.from_frames(rowptr, col, pval_d, t(b["frames"]))
             opQf.signed.csr().sell(); opQf.signed.csr_t().sell()
-
-            def step_f():
-                xs.grad = None; xv.grad = None
-                Ws = get_Batch_Wjxs(xs, opP, scales_type="dyadic", J=args.J)
-                Wv = get_Batch_Wjxs(xv, opQf, scales_type="dyadic", J=args.J)
-                Ws.backward(gs); Wv.backward(gv)
-            for _ in range(args.warmup):
-                step_f()
-            torch.cuda.synchronize(); tf0 = time.perf_counter()
-            for _ in range(args.steps):
-                step_f()
-            torch.cuda.synchronize(); dtf = time.perf_counter() - tf0
-            out["factored_Q_variant"] = {"value": args.graphs * args.steps / dtf, "unit": "graphs/s",
-                                         "ms_per_step": dtf / args.steps * 1e3,
-                                         "note": "opt-in operator format, not the headline; see DESIGN.md (factored vector operator)"}
+            out["variants"]["factored_from_frames"] = variant(opQf, "factored operator built from the true frames (the builder's own route, "
+                                                                    "FactoredVectorOperator.from_frames)")
+            del opQf
+        if world == 1 and not args.no_fresh_coo:
+            out["dropin_fresh_coo"] = bench_fresh_coo(b, dev, t, args, xs.detach(), xv.detach())
         if c3 is not None:
             out["cfg3"] = bench_cfg3(c3, dev, t, args)
         if not args.no_cpu_baseline and world == 1:

@@ -59,7 +59,9 @@ SIGNATURES = {
     "escat_sell_pack_workspace_bytes": (sz, [i64, ci]),
     "escat_sell_pack_plan": (ci, [vp, i64, vp, ci, ci, ci, ci, vp, sz, vp, vp]),
     "escat_sell_pack_fill": (ci, [vp, vp, vp, vp, i64, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]),
+    "escat_sell_pack_fill_unplanned": (ci, [vp, vp, vp, vp, i64, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]),
     "escat_sell_pack_refill": (ci, [vp, vp, i64, vp, ci, ci, vp, vp, sz, vp, vp, vp]),
+    "escat_sell_pack_refill_signed": (ci, [vp, vp, vp, i64, vp, ci, vp, vp, sz, vp, vp, vp, vp, vp]),
     "escat_sell_pack_refill_half": (ci, [vp, vp, i64, vp, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp]),
     "escat_ingest_coo": (ci, [vp, vp, i64, i64, ci, vp, vp, vp, vp]),
     "escat_row_cover": (ci, [vp, vp, i64, vp, vp]),
@@ -71,8 +73,8 @@ SIGNATURES = {
     "escat_vector_invariants_bwd_f32": (ci, [vp, vp, vp, i64, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "escat_rotate_frames_f32": (ci, [vp, vp, vp, i64, ci, ci, vp]),
     "escat_infogain_divergence_f32": (ci, [vp, vp, i64, ci, ci, ci, ci, ci, ctypes.c_float, ci, vp, vp, vp]),
-    "escat_recover_factored_lds_bytes": (sz, [ci]),
-    "escat_recover_factored": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, vp, vp, vp]),
+    "escat_recover_factored_lds_bytes": (sz, [ci, ci]),
+    "escat_recover_factored": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, ci, vp, vp, vp, vp]),
     "escat_lookup3": (ctypes.c_uint32, [ctypes.c_char_p, sz, ctypes.c_uint32]),
     "escat_build_workspace_bytes": (sz, [i64, ci, ci]),
     "escat_build_knn_P": (ci, [vp, vp, ci, i64, ci, ci, vp, vp, vp, i64, vp, vp, sz, vp]),

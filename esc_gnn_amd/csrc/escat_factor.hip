@@ -18,13 +18,16 @@
 //      component's gauge: G_i <- G_i V (with G_root = I alone the check below fails wherever the sign field is not a
 //      pure gauge: 13-49 % of the edges of the builder goldens carry a -1); two Newton steps of the joint
 //      diagonalisation, with the signs then known, sharpen V beyond what the eigenvalue gaps of the sum allow;
-//   4. two relaxation sweeps G_i <- polar(sum_j R_ij G_j S_ij) take the rounding drift of the tree walk out (the blocks
+//   4. a relaxation sweep G_i <- polar(sum_j p_ij R_ij G_j S_ij) take the rounding drift of the tree walk out (the blocks
 //      are fp32: depth x 1e-7 of drift would otherwise show in the bank at the 1e-5 level);
 //   5. S_ij = sign diag(G_i^T R_ij G_j); the reconstruction error max |p_ij G_i S_ij G_j^T - Q_ij| over all blocks is
 //      returned -- the caller accepts the factorisation iff it is below its tolerance.
 #include "escat_dev.h"
 #include <limits.h>
 
+#ifndef ESCAT_RECOVER_SWEEPS
+#define ESCAT_RECOVER_SWEEPS 1
+#endif
 namespace {
 __device__ __forceinline__ void mm(const double *A, const double *B, double *C)        // C = A B
 {
@@ -50,6 +53,12 @@ __device__ __forceinline__ double load_R(const float *__restrict__ blk, int64_t 
 #pragma unroll
     for (int q = 0; q < 9; ++q) R[q] = b[q] * inv;
     return p;
+}
+// the block as it is, p_ij R_ij (the passes that only need directions, signs or p-weighted sums skip the sqrt and the division)
+__device__ __forceinline__ void load_B(const float *__restrict__ blk, int64_t e, double *B)
+{
+#pragma unroll
+    for (int q = 0; q < 9; ++q) B[q] = (double)blk[e * 9 + q];
 }
 // orthogonal polar factor of a nonsingular 3x3 matrix (Newton: X <- (X + X^-T) / 2); false if (near) singular
 __device__ bool polar3(double *X)
@@ -80,7 +89,7 @@ __device__ void jacobi3(const double *S6, double *V)
     for (int q = 0; q < 9; ++q) V[q] = (q % 4 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 16; ++sweep) {
         const double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
-        if (off < 1e-300) break;
+        if (off <= 1e-17 * (fabs(A[0]) + fabs(A[4]) + fabs(A[8]) + off)) break;
         for (int k = 0; k < 3; ++k) {
             const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;       // (0,1) (0,2) (1,2)
             const double apq = A[p * 3 + q];
@@ -104,23 +113,61 @@ __device__ void jacobi3(const double *S6, double *V)
     }
 }
 
+// fixed-order block sum of K doubles per thread: shuffles inside a wave, then the (NT / 64) wave partials through LDS by
+// thread 0; the result lands in red[0..K).  The same order on every run: the same frames on every run.
+template <int NT, int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *red)
+{
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v[q] += __shfl_xor(v[q], m, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                              // (red may still be read from the previous use)
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < K; ++q) red[8 + wave * K + q] = v[q];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int q = 0; q < K; ++q) {
+            double t = 0.0;
+            for (int w = 0; w < NT / 64; ++w) t += red[8 + w * K + q];
+            red[q] = t;
+        }
+    __syncthreads();
+}
+
+// LDS: G (max_rows x 9 doubles) | red (8 + NT/64 x 6 doubles) | state (max_rows ints) | colL (max_part_nnz ushorts: the
+// part-local column of every entry, read once from HBM -- the breadth-first walk scans it once per level)
 template <int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 4)       // <= 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
 k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ blk,
-                 const int *__restrict__ part_ptr, int max_rows, float *__restrict__ frames_out, float *__restrict__ val3_out,
-                 float *__restrict__ err_out /* [0] max reconstruction error (float bits, atomicMax), [1] flag: malformed */)
+                 const int *__restrict__ part_ptr, int max_rows, int max_part_nnz, float *__restrict__ frames_out,
+                 float *__restrict__ val3_out, float *__restrict__ err_out /* max reconstruction error (float bits, atomicMax) */)
 {
     extern __shared__ __align__(16) double sm[];
-    double *G = sm, *G2 = sm + (size_t)max_rows * 9, *red = G2 + (size_t)max_rows * 9;
-    int *state = reinterpret_cast<int *>(red + NT * 6);   // -1 unvisited, >= 0 depth in the component being walked, -2 done
+    double *G = sm, *red = sm + (size_t)max_rows * 9;
+    int *state = reinterpret_cast<int *>(red + 8 + (NT / 64) * 6);     // -1 unvisited, >= 0 depth in the component being walked, -2 done
+    unsigned short *colL = reinterpret_cast<unsigned short *>(state + max_rows);
     __shared__ int s_root;
     __shared__ double s_V[9];
     const int part = blockIdx.x, gs = part_ptr[part], rows = part_ptr[part + 1] - gs;
     const int i = threadIdx.x;
     const bool own = i < rows;
-    const int e0 = own ? rowptr[gs + i] : 0, e1 = own ? rowptr[gs + i + 1] : 0;
+    const int eb = rowptr[gs], ne = rowptr[gs + rows] - eb;      // the part's entries
+    const int e0 = own ? rowptr[gs + i] : eb, e1 = own ? rowptr[gs + i + 1] : eb;
+    bool malformed = ne > max_part_nnz;
+    for (int k = i; k < ne && k < max_part_nnz; k += NT) {
+        const int j = col[eb + k] - gs;
+        if (j < 0 || j >= rows) malformed = true;              // an entry that leaves the part: not a block-diagonal batch
+        colL[k] = (unsigned short)(j < 0 || j >= rows ? 0 : j);
+    }
     if (own) state[i] = -1;
-    __syncthreads();
+    if (__syncthreads_or(malformed)) {
+        if (i == 0) atomicMax(reinterpret_cast<unsigned *>(err_out), __float_as_uint(1e30f));
+        return;
+    }
+    const unsigned short *cl = colL + (e0 - eb);
+    const int deg = e1 - e0;
     for (;;) {                                    // one connected component per trip
         if (i == 0) s_root = INT_MAX;
         __syncthreads();
@@ -136,12 +183,11 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
         for (int cur = 0;; ++cur) {               // breadth-first levels
             int found = 0;
             if (own && state[i] == -1)
-                for (int e = e0; e < e1; ++e) {
-                    const int j = col[e] - gs;
-                    if (j < 0 || j >= rows) continue;
+                for (int k = 0; k < deg; ++k) {
+                    const int j = cl[k];
                     if (state[j] == cur) {        // (a node set to cur + 1 in this very trip is not taken for a parent)
                         double R[9], Gi[9];
-                        if (load_R(blk, e, R) > 0.0) {
+                        if (load_R(blk, e0 + k, R) > 0.0) {
                             mm(R, G + j * 9, Gi);           // R_ij = G_i G_j^T on a tree edge
                             for (int q = 0; q < 9; ++q) G[i * 9 + q] = Gi[q];
                             found = 1;
@@ -157,28 +203,20 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
         double S6[6] = {0, 0, 0, 0, 0, 0};
         const bool mine = own && state[i] >= 0;
         if (mine)
-            for (int e = e0; e < e1; ++e) {
-                const int j = col[e] - gs;
-                if (j < 0 || j >= rows) continue;       // (a neighbour is in this component by definition)
+            for (int k = 0; k < deg; ++k) {       // (a neighbour is in this component by definition)
                 double R[9], M[9], H[9];
-                if (!(load_R(blk, e, R) > 0.0)) continue;
-                mm(R, G + j * 9, M);
+                load_B(blk, e0 + k, R);                // p_ij R_ij: the weight of the edge becomes w p_ij, as good as w
+                mm(R, G + cl[k] * 9, M);
                 mtm(G + i * 9, M, H);
                 // (a mixing hash: with a multiplicative one the DIFFERENCE of two weights depends on the difference of the entry
                 // indices only, and the regular patterns of small graphs made two eigenvalues of the sum coincide to 1e-7)
-                unsigned hsh = (unsigned)e;
+                unsigned hsh = (unsigned)(e0 + k);
                 hsh ^= hsh >> 16; hsh *= 0x85ebca6bu; hsh ^= hsh >> 13; hsh *= 0xc2b2ae35u; hsh ^= hsh >> 16;
                 const double w = 0.5 + (double)(hsh >> 8) * (1.0 / 16777216.0);
                 S6[0] += w * H[0]; S6[1] += w * 0.5 * (H[1] + H[3]); S6[2] += w * 0.5 * (H[2] + H[6]);
                 S6[3] += w * H[4]; S6[4] += w * 0.5 * (H[5] + H[7]); S6[5] += w * H[8];
             }
-        for (int q = 0; q < 6; ++q) red[i * 6 + q] = S6[q];
-        __syncthreads();
-        for (int h = NT / 2; h >= 1; h >>= 1) {   // fixed-order tree sum: the same V on every run
-            if (i < h)
-                for (int q = 0; q < 6; ++q) red[i * 6 + q] += red[(i + h) * 6 + q];
-            __syncthreads();
-        }
+        block_sum<NT, 6>(S6, red);
         if (i == 0) jacobi3(red, s_V);
         __syncthreads();
         if (mine) {
@@ -188,30 +226,23 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
         }
         __syncthreads();
         // The eigenvectors of the weighted sum are only as sharp as its eigenvalue gaps allow.  With the signs now known,
-        // two Newton steps of the joint diagonalisation proper: the rotation exp(W), W antisymmetric, that takes the
+        // Newton steps of the joint diagonalisation proper: the rotation exp(W), W antisymmetric, that takes the
         // off-diagonals of ALL holonomies out to first order, W_ab = -sum_e (d_a - d_b) H_e,ab / sum_e (d_a - d_b)^2.
         for (int it = 0; it < 2; ++it) {
             double acc[6] = {0, 0, 0, 0, 0, 0};
             if (mine)
-                for (int e = e0; e < e1; ++e) {
-                    const int j = col[e] - gs;
-                    if (j < 0 || j >= rows) continue;
+                for (int k = 0; k < deg; ++k) {
                     double R[9], M[9], H[9];
-                    if (!(load_R(blk, e, R) > 0.0)) continue;
-                    mm(R, G + j * 9, M);
+                    load_B(blk, e0 + k, R);            // H = p_ij x holonomy: a least-squares fit weighted by p_ij
+                    mm(R, G + cl[k] * 9, M);
                     mtm(G + i * 9, M, H);
                     const double d0 = H[0] < 0.0 ? -1.0 : 1.0, d1 = H[4] < 0.0 ? -1.0 : 1.0, d2 = H[8] < 0.0 ? -1.0 : 1.0;
-                    acc[0] += (d0 - d1) * 0.5 * (H[1] + H[3]); acc[3] += (d0 - d1) * (d0 - d1);
-                    acc[1] += (d0 - d2) * 0.5 * (H[2] + H[6]); acc[4] += (d0 - d2) * (d0 - d2);
-                    acc[2] += (d1 - d2) * 0.5 * (H[5] + H[7]); acc[5] += (d1 - d2) * (d1 - d2);
+                    const double pw = (fabs(H[0]) + fabs(H[4]) + fabs(H[8])) * (1.0 / 3.0);      // ~ p_ij
+                    acc[0] += (d0 - d1) * 0.5 * (H[1] + H[3]); acc[3] += (d0 - d1) * (d0 - d1) * pw;
+                    acc[1] += (d0 - d2) * 0.5 * (H[2] + H[6]); acc[4] += (d0 - d2) * (d0 - d2) * pw;
+                    acc[2] += (d1 - d2) * 0.5 * (H[5] + H[7]); acc[5] += (d1 - d2) * (d1 - d2) * pw;
                 }
-            for (int q = 0; q < 6; ++q) red[i * 6 + q] = acc[q];
-            __syncthreads();
-            for (int h = NT / 2; h >= 1; h >>= 1) {
-                if (i < h)
-                    for (int q = 0; q < 6; ++q) red[i * 6 + q] += red[(i + h) * 6 + q];
-                __syncthreads();
-            }
+            block_sum<NT, 6>(acc, red);
             if (i == 0) {
                 const double w01 = red[3] > 0.0 ? -red[0] / red[3] : 0.0, w02 = red[4] > 0.0 ? -red[1] / red[4] : 0.0,
                              w12 = red[5] > 0.0 ? -red[2] / red[5] : 0.0;
@@ -219,59 +250,63 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
                 if (!polar3(U))
                     for (int q = 0; q < 9; ++q) U[q] = (q % 4 == 0) ? 1.0 : 0.0;
                 for (int q = 0; q < 9; ++q) s_V[q] = U[q];
+                red[6] = fabs(w01) + fabs(w02) + fabs(w12);
             }
             __syncthreads();
-            if (mine) {
+            const bool small = red[6] < 1e-4;    // (uniform) Newton converges quadratically: after a correction this small
+            if (mine) {                           // the next one would be ~1e-8, below the blocks' own fp32 noise
                 double Gi[9];
                 mm(G + i * 9, s_V, Gi);
                 for (int q = 0; q < 9; ++q) G[i * 9 + q] = Gi[q];
             }
             __syncthreads();
+            if (small) break;
         }
         if (mine) state[i] = -2;
         __syncthreads();
     }
-    // relaxation: every frame becomes the orthogonal factor closest to what its neighbours say it is
-    for (int sweep = 0; sweep < 2; ++sweep) {
+    // relaxation: every frame becomes the orthogonal factor closest to what its neighbours say it is (in place: all new
+    // frames are formed from the old ones, then written)
+    for (int sweep = 0; sweep < ESCAT_RECOVER_SWEEPS; ++sweep) {
+        double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool upd = false;
         if (own) {
-            double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int e = e0; e < e1; ++e) {
-                const int j = col[e] - gs;
-                if (j == i || j < 0 || j >= rows) continue;
+            for (int k = 0; k < deg; ++k) {
+                const int j = cl[k];
+                if (j == i) continue;
                 double R[9], M[9];
-                const double p = load_R(blk, e, R);
-                if (!(p > 0.0)) continue;
-                mm(R, G + j * 9, M);              // R_ij G_j ~ G_i S_ij
+                load_B(blk, e0 + k, R);
+                mm(R, G + j * 9, M);              // p_ij R_ij G_j ~ p_ij G_i S_ij: weighted by p_ij, heavier edges say more
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const double d = G[i * 9 + c] * M[c] + G[i * 9 + 3 + c] * M[3 + c] + G[i * 9 + 6 + c] * M[6 + c];
-                    const double s = d < 0.0 ? -p : p;      // weighted by p_ij: heavier edges say more
-                    A[c] += s * M[c]; A[3 + c] += s * M[3 + c]; A[6 + c] += s * M[6 + c];
+                    const double sg = d < 0.0 ? -1.0 : 1.0;
+                    A[c] += sg * M[c]; A[3 + c] += sg * M[3 + c]; A[6 + c] += sg * M[6 + c];
                 }
             }
-            if (!polar3(A))
-                for (int q = 0; q < 9; ++q) A[q] = G[i * 9 + q];
-            for (int q = 0; q < 9; ++q) G2[i * 9 + q] = A[q];
+            upd = polar3(A);
         }
         __syncthreads();
-        double *t = G; G = G2; G2 = t;
+        if (upd)
+            for (int q = 0; q < 9; ++q) G[i * 9 + q] = A[q];
+        __syncthreads();
     }
     // signs, values, reconstruction error
     float err = 0.f;
     if (own) {
         for (int q = 0; q < 9; ++q) frames_out[(int64_t)(gs + i) * 9 + q] = (float)G[i * 9 + q];
-        for (int e = e0; e < e1; ++e) {
-            const int j = col[e] - gs;
-            if (j < 0 || j >= rows) { err = 1e30f; continue; }      // an entry that leaves the part: not a block-diagonal batch
+        for (int k = 0; k < deg; ++k) {
+            const int j = cl[k];
+            const int64_t e = e0 + k;
             double R[9], M[9];
             const double p = load_R(blk, e, R);
             mm(R, G + j * 9, M);
-            double s[3];
+            double sg[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const double d = G[i * 9 + c] * M[c] + G[i * 9 + 3 + c] * M[3 + c] + G[i * 9 + 6 + c] * M[6 + c];
-                s[c] = d < 0.0 ? -1.0 : 1.0;
-                val3_out[(int64_t)e * 3 + c] = (float)(p * s[c]);
+                sg[c] = d < 0.0 ? -1.0 : 1.0;
+                val3_out[e * 3 + c] = (float)(p * sg[c]);
             }
             // p G_i S G_j^T against the block as given
 #pragma unroll
@@ -280,8 +315,8 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
                 for (int b = 0; b < 3; ++b) {
                     double v = 0.0;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v += G[i * 9 + a * 3 + c] * s[c] * G[j * 9 + b * 3 + c];
-                    err = fmaxf(err, fabsf((float)(p * v - (double)blk[(int64_t)e * 9 + a * 3 + b])));
+                    for (int c = 0; c < 3; ++c) v += G[i * 9 + a * 3 + c] * sg[c] * G[j * 9 + b * 3 + c];
+                    err = fmaxf(err, fabsf((float)(p * v - (double)blk[e * 9 + a * 3 + b])));
                 }
         }
     }
@@ -292,31 +327,33 @@ k_recover_frames(const int *__restrict__ rowptr, const int *__restrict__ col, co
 }
 }   // namespace
 
-extern "C" size_t escat_recover_factored_lds_bytes(int max_part_rows)
+extern "C" size_t escat_recover_factored_lds_bytes(int max_part_rows, int max_part_nnz)
 {
     const int NT = max_part_rows <= 256 ? 256 : 512;
-    return ((size_t)max_part_rows * 18 + (size_t)NT * 6) * sizeof(double) + (size_t)max_part_rows * sizeof(int);
+    return ((size_t)max_part_rows * 9 + 8 + (size_t)(NT / 64) * 6) * sizeof(double) + (size_t)max_part_rows * sizeof(int)
+           + (((size_t)max_part_nnz + 7) & ~(size_t)7) * sizeof(unsigned short);
 }
 
 extern "C" int escat_recover_factored(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
-                                      const int32_t *part_ptr, int n_parts, int max_part_rows, float *frames_out,
-                                      float *val3_out, float *max_err, void *stream)
+                                      const int32_t *part_ptr, int n_parts, int max_part_rows, int max_part_nnz,
+                                      float *frames_out, float *val3_out, float *max_err, void *stream)
 {
     if (!rowptr || !col || !blk || !part_ptr || !frames_out || !val3_out || !max_err) return fail(ESCAT_EINVAL, "NULL pointer");
     if (nb <= 0 || nnzb <= 0 || n_parts <= 0) return fail(ESCAT_EINVAL, "empty operator");
     if (max_part_rows < 1 || max_part_rows > 512) return fail(ESCAT_ERANGE, "parts of up to %d block rows: at most 512", max_part_rows);
+    if (max_part_nnz < 1) return fail(ESCAT_EINVAL, "max_part_nnz=%d", max_part_nnz);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = escat_recover_factored_lds_bytes(max_part_rows);
-    if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "recovery needs %zu B of LDS", lds);
+    const size_t lds = escat_recover_factored_lds_bytes(max_part_rows, max_part_nnz);
+    if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "recovery needs %zu B of LDS (parts of %d entries)", lds, max_part_nnz);
     int rc;
     if (max_part_rows <= 256) {
         rc = set_lds(k_recover_frames<256>, lds); if (rc) return rc;
         hipLaunchKernelGGL((k_recover_frames<256>), dim3(n_parts), dim3(256), lds, st, rowptr, col, blk, part_ptr, max_part_rows,
-                           frames_out, val3_out, max_err);
+                           max_part_nnz, frames_out, val3_out, max_err);
     } else {
         rc = set_lds(k_recover_frames<512>, lds); if (rc) return rc;
         hipLaunchKernelGGL((k_recover_frames<512>), dim3(n_parts), dim3(512), lds, st, rowptr, col, blk, part_ptr, max_part_rows,
-                           frames_out, val3_out, max_err);
+                           max_part_nnz, frames_out, val3_out, max_err);
     }
     CHECK_LAUNCH("escat_recover_factored");
     return ESCAT_OK;

@@ -211,6 +211,40 @@ k_pack_refill_half(const int *__restrict__ rowptr, const float *__restrict__ val
     if (bad) *not_exact = 1;
 }
 
+// the same for a sign-bit pack (values_per_entry 3 given as |value| + sign bits, escat_sell.val_planes = 4) on the plan of a
+// pack with the same pattern, capacity and layout (P's own pack, typically): the magnitudes, and the shared LDS rows with
+// the entries' sign bits in bits 11..13 of every 16-bit field.
+__global__ void __launch_bounds__(256)
+k_pack_refill_signed(const int *__restrict__ rowptr, const float *__restrict__ mag, const int *__restrict__ sign_bits,
+                     const int *__restrict__ part_ptr, const int *__restrict__ perm, const int *__restrict__ doff_,
+                     const int *__restrict__ poff_, const signed char *__restrict__ ent, const unsigned *__restrict__ lc,
+                     int nsl, int n_slices, float *__restrict__ val_out, unsigned *__restrict__ lc_out)
+{
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n_slices) return;
+    const int gs = part_ptr[s / nsl];
+    const int r = perm[(int64_t)s * 64 + lane];
+    const int doff = doff_[s], w = doff_[s + 1] - doff, poff = poff_[s];
+    const int64_t e0 = r >= 0 ? rowptr[gs + r] : 0;
+    for (int k0 = 0; k0 < w; k0 += 4) {           // four slots = two LDS-row pairs per trip
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = k0 + u < w ? (int)ent[(int64_t)(doff + k0 + u) * 64 + lane] : -1;
+        float m[4]; unsigned sb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[u] = j[u] >= 0 ? mag[e0 + j[u]] : 0.f;
+            sb[u] = j[u] >= 0 ? ((unsigned)sign_bits[e0 + j[u]] & 7u) << 11 : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < w) val_out[(int64_t)(doff + k0 + u) * 64 + lane] = m[u];
+        const int64_t o = (int64_t)(poff + k0 / 2) * 64 + lane;
+        lc_out[o] = lc[o] | sb[0] | (sb[1] << 16);
+        lc_out[o + 64] = lc[o + 64] | sb[2] | (sb[3] << 16);
+    }
+}
+
 // ------------------------------------------------------------------ plan + fill, one wave per slice
 // V: floats per entry in `val` (1 scalar, 3 one per channel, 9 a 3x3 block); SIGNED (V == 3 input given as |value| +
 // sign bits): one plane of magnitudes, the three signs in bits 11..13 of the entry's 16-bit LDS-row field.
@@ -220,7 +254,7 @@ k_pack_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const f
             const int *__restrict__ sign_bits, const int *__restrict__ part_ptr, const int *__restrict__ perm,
             const int *__restrict__ pos_of_row, const int *__restrict__ doff_, const int *__restrict__ poff_,
             int dmax, int nsl, float *__restrict__ val_out, unsigned *__restrict__ lc_out, int *__restrict__ lane_meta,
-            int *__restrict__ slot_of_e, int *__restrict__ lc_of_e, signed char *__restrict__ ent_out)
+            int *__restrict__ slot_of_e, int *__restrict__ lc_of_e, signed char *__restrict__ ent_out, int plan)
 {
     __shared__ short cols[64][33];                 // LDS row candidates (copy A) of each lane's kept entries
     __shared__ signed char ent_of_slot[64][32];    // after planning: which entry sits in slot k (-1: none)
@@ -253,6 +287,14 @@ k_pack_fill(const int *__restrict__ rowptr, const int *__restrict__ col, const f
     const int zslot = rows & 15;
     for (int k = 0; k < w; ++k) {
         const bool padded = k >= cnt;
+        if (!plan) {                               // unplanned pack: entries in row order, copy A (an operator used once
+            if (!padded) {                         // is not worth the milliseconds of the matching)
+                ent_of_slot[lane][k] = (signed char)k;
+                row_of_slot[lane][k] = (unsigned short)cols[lane][k];
+                if (slot_of_e) { slot_of_e[e0 + k] = k; lc_of_e[e0 + k] = cols[lane][k]; }
+            }
+            continue;
+        }
         const unsigned long long pm = __ballot(padded);
         if constexpr (LAYOUT == 1) {
             // Layout-1 packs: a MAXIMUM MATCHING of the lane group's 16 lanes onto the 16 bank slots instead of the
@@ -486,11 +528,37 @@ extern "C" int escat_sell_pack_plan(const int32_t *rowptr, int64_t n, const int3
     return ESCAT_OK;
 }
 
+static int pack_fill(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *sign_bits,
+                     int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
+                     const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
+                     float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
+                     int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream, int plan);
+
 extern "C" int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *sign_bits,
                                     int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
                                     const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
                                     float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
                                     int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream)
+{
+    return pack_fill(rowptr, col, val, sign_bits, n, nnz, part_ptr, n_parts, values_per_entry, dims, workspace, workspace_bytes,
+                     val_out, lc_out, lane_meta_out, slot_of_e, lc_of_e, ent_of_slot, stream, 1);
+}
+
+extern "C" int escat_sell_pack_fill_unplanned(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *sign_bits,
+                                              int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
+                                              const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
+                                              float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
+                                              int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream)
+{
+    return pack_fill(rowptr, col, val, sign_bits, n, nnz, part_ptr, n_parts, values_per_entry, dims, workspace, workspace_bytes,
+                     val_out, lc_out, lane_meta_out, slot_of_e, lc_of_e, ent_of_slot, stream, 0);
+}
+
+static int pack_fill(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *sign_bits,
+                     int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
+                     const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
+                     float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
+                     int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream, int plan)
 {
     if (!rowptr || !col || !val || !part_ptr || !dims || !workspace || !val_out || !lc_out || !lane_meta_out)
         return fail(ESCAT_EINVAL, "NULL pointer");
@@ -510,7 +578,7 @@ extern "C" int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, c
     if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
 #define GO(VV, SG, LY) hipLaunchKernelGGL((k_pack_fill<VV, SG, LY>), dim3((unsigned)ns), dim3(64), 0, st, rowptr, col, val, sign_bits, \
         part_ptr, ws.perm, ws.pos, ws.doff, ws.poff, dims->dmax, dims->slices_per_part, val_out, lc_out, lane_meta_out, slot_of_e, lc_of_e, \
-        (signed char *)ent_of_slot)
+        (signed char *)ent_of_slot, plan)
     const int ly = dims->layout;
     if (values_per_entry == 9) { if (ly) GO(9, false, 1); else GO(9, false, 0); }
     else if (values_per_entry == 1) { if (ly) GO(1, false, 1); else GO(1, false, 0); }
@@ -567,6 +635,27 @@ extern "C" int escat_sell_pack_refill_half(const int32_t *rowptr, const float *b
                        ws.poff, (const signed char *)ent_of_slot, lc, dims->slices_per_part, (int)ns, (uint4 *)half_val_out,
                        half_aux_out, not_exact);
     CHECK_LAUNCH("escat_sell_pack_refill_half");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_sell_pack_refill_signed(const int32_t *rowptr, const float *mag, const int32_t *sign_bits, int64_t n,
+                                             const int32_t *part_ptr, int n_parts, const escat_sell_dims *dims,
+                                             const void *workspace, size_t workspace_bytes, const int8_t *ent_of_slot,
+                                             const uint32_t *lc, float *val_out, uint32_t *lc_out, void *stream)
+{
+    if (!rowptr || !mag || !sign_bits || !part_ptr || !dims || !workspace || !ent_of_slot || !lc || !val_out || !lc_out)
+        return fail(ESCAT_EINVAL, "NULL pointer");
+    const int64_t ns = dims->n_slices;
+    if (ns != (int64_t)n_parts * dims->slices_per_part) return fail(ESCAT_EINVAL, "dims do not belong to this operator");
+    if (workspace_bytes < pack_ws_ints(n, (int64_t)n_parts * 8) * sizeof(int)) return fail(ESCAT_EWORKSPACE, "workspace too small");
+    PackWs ws = pack_ws(const_cast<void *>(workspace), n, ns);
+    hipStream_t st = S(stream);
+    hipError_t e = hipMemsetAsync(val_out + dims->total_d * 64, 0, 64 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(lc_out + dims->total_p * 64, 0, 64 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_pack_refill_signed, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, st, rowptr, mag, sign_bits, part_ptr, ws.perm,
+                       ws.doff, ws.poff, (const signed char *)ent_of_slot, lc, dims->slices_per_part, (int)ns, val_out, lc_out);
+    CHECK_LAUNCH("escat_sell_pack_refill_signed");
     return ESCAT_OK;
 }
 

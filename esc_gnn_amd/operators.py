@@ -205,6 +205,13 @@ HALF_MAX_DMAX = 20
 FACTOR_MODE = os.environ.get("ESCAT_Q_FACTOR", "auto")
 FACTOR_TOL = 1e-6
 
+# How much to invest in an operator at ingest.  "full" (default): everything that makes the chains fast -- the matching
+# slot plan of the SELL pack, the factored form of Q -- a few milliseconds per 4096-graph batch that pay back after a
+# handful of steps (stores, cached batches, repeated epochs).  "single_use": for callers that hand over FRESH tensors
+# every step (the reference's DataLoader, models/escgnn_data_classes.py:137-142): unplanned packs, no recovery of the
+# factored form; the half-valued pack is still taken when the values are exact in fp16 (it costs less than the fp32 one).
+INGEST_POLICY = os.environ.get("ESCAT_INGEST", "full")
+
 
 class Sell:
     """
@@ -241,9 +248,10 @@ class Sell:
         key = (form.rowptr.data_ptr(), form.col.data_ptr(), form.rowptr._version, form.col._version,
                form.part_ptr.data_ptr(), form.n_parts, form.max_part_rows, n, nnz, self.layout, str(dev))
         shared = None
-        if signed is None and not keep_plan and layout is None:
+        if not keep_plan and layout is None:
             for cap_key, cand in _PLAN_CACHE.items():
-                if cap_key[:-1] == key and cand._pattern[0] is form.rowptr and cand._pattern[1] is form.col \
+                if cand.layout == self.layout and cand._ent is not None and cand.planned == (INGEST_POLICY != "single_use") \
+                        and self._same_pattern(cand, form, cap_key[:-1] == key) \
                         and cand.dmax == self._capacity_for(V, cand):
                     shared = cand
                     break
@@ -253,9 +261,19 @@ class Sell:
             if shared is not None:
                 dims = shared._dims
                 self.lc, self.lane_meta, ws, self._ent = shared.lc, shared.lane_meta, shared._ws, shared._ent
+                self.planned = shared.planned
                 if V == 9:
                     self._try_half(lib, form, dims, ws, st)
-                if self.half_val is None or HALF_MODE == "both":
+                if signed is not None:           # |value| + sign bits: own lc = the shared rows with the signs in bits 11..13
+                    self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
+                    self.lc = torch.empty(dims.lc_words, dtype=torch.int32, device=dev)
+                    bits = signed[2].to(torch.int32).contiguous()
+                    _lib.check(lib.escat_sell_pack_refill_signed(vp(form.rowptr), vp(signed[1]), vp(bits), n, vp(form.part_ptr),
+                                                                 form.n_parts, ctypes.byref(dims), vp(shared._ws), shared._ws.numel() * 4,
+                                                                 vp(shared._ent), vp(shared.lc), vp(self.val), vp(self.lc), st),
+                               "escat_sell_pack_refill_signed")
+                    self._ent = None             # (its lc carries sign bits: not a plan others may share)
+                elif self.half_val is None or HALF_MODE == "both":
                     self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
                     _lib.check(lib.escat_sell_pack_refill(vp(form.rowptr), vp(form.val), n, vp(form.part_ptr), form.n_parts, V,
                                                           ctypes.byref(dims), vp(shared._ws), shared._ws.numel() * 4,
@@ -281,7 +299,9 @@ class Sell:
                 else:
                     src_val, bits = form.val, None
                 null = ctypes.c_void_p(0)
-                _lib.check(lib.escat_sell_pack_fill(vp(form.rowptr), vp(form.col), vp(src_val),
+                self.planned = INGEST_POLICY != "single_use"
+                fill = lib.escat_sell_pack_fill if self.planned else lib.escat_sell_pack_fill_unplanned
+                _lib.check(fill(vp(form.rowptr), vp(form.col), vp(src_val),
                                                     vp(bits) if bits is not None else null, n, nnz,
                                                     vp(form.part_ptr), form.n_parts, V, ctypes.byref(dims), vp(ws), ws.numel() * 4,
                                                     vp(self.val), vp(self.lc), vp(self.lane_meta),
@@ -305,16 +325,34 @@ class Sell:
         self.pos_of_row = ws[o:o + n]
         self._ws = ws
         self._pattern = (form.rowptr, form.col)          # keeps the key's tensors alive (identity is part of the key)
+        self._parts = (form.part_ptr, form.n_parts, form.max_part_rows)
         self.total_d = int(dims.total_d)
         if shared is None and self._ent is not None and layout is None:
             _PLAN_CACHE.clear()                          # one pattern at a time: batches come and go
             _PLAN_CACHE[key + (self.dmax,)] = self
+
+    @staticmethod
+    def _same_pattern(cand, form, same_key: bool) -> bool:
+        """does `form` have the pattern and parts the pack `cand` was planned on?  By identity of the tensors (an operator
+        and its transpose; operators built on the same arrays), else by content: P and Q of one batch arrive as separate
+        COO tensors (models/escgnn_data_classes.py:137-142) whose canonical patterns are equal element for element."""
+        crp, ccl = cand._pattern
+        if same_key and crp is form.rowptr and ccl is form.col:
+            return True
+        cpp = cand._parts
+        if crp.shape != form.rowptr.shape or ccl.shape != form.col.shape or cpp[0].shape != form.part_ptr.shape \
+                or cpp[1] != form.n_parts or cpp[2] != form.max_part_rows or crp.device != form.rowptr.device:
+            return False
+        return bool(torch.equal(crp, form.rowptr)) and bool(torch.equal(cpp[0], form.part_ptr)) and bool(torch.equal(ccl, form.col))
 
     def _try_half(self, lib, form, dims, ws, st):
         """build the half-valued form of a BSR-3 pack on the plan at hand; keeps it iff every value is exact in fp16."""
         import ctypes
         from . import _lib
         if HALF_MODE == "0" or self.layout != 1 or int(dims.dmax) > HALF_MAX_DMAX:
+            return
+        v = form.val.reshape(-1)[:: max(1, form.val.numel() // 4096)]       # a cheap probe before the full pass: a few
+        if not bool((v.to(torch.float16).to(torch.float32) == v).all()):     # thousand values settle most operators
             return
         dev = form.rowptr.device
         vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
@@ -742,7 +780,7 @@ class ScatterOperator:
         if self._factored is None:
             self._factored = False
             b = self._bsr
-            if b is not None and FACTOR_MODE != "0" and b.val.is_cuda and b.nnz > 0 and 0 < b.max_part_rows <= SELL_MAX_PART_ROWS \
+            if b is not None and FACTOR_MODE != "0" and INGEST_POLICY != "single_use" and b.val.is_cuda and b.nnz > 0 and 0 < b.max_part_rows <= SELL_MAX_PART_ROWS \
                     and self.row_perm is None and not self.values_look_fp16():
                 import ctypes
                 from . import _lib
@@ -752,9 +790,13 @@ class ScatterOperator:
                 val3 = torch.empty((b.nnz, 3), dtype=torch.float32, device=dev)
                 err = torch.zeros(1, dtype=torch.float32, device=dev)
                 vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+                pe = b.rowptr[b.part_ptr.long()]
+                max_part_nnz = int((pe[1:] - pe[:-1]).max())
+                if lib.escat_recover_factored_lds_bytes(b.max_part_rows, max_part_nnz) > 160 * 1024:
+                    return None
                 with torch.cuda.device(dev):
                     _lib.check(lib.escat_recover_factored(vp(b.rowptr), vp(b.col), vp(b.val), b.n, b.nnz, vp(b.part_ptr), b.n_parts,
-                                                          b.max_part_rows, vp(frames), vp(val3), vp(err),
+                                                          b.max_part_rows, max_part_nnz, vp(frames), vp(val3), vp(err),
                                                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
                                "escat_recover_factored")
                 scale = float(b.val.abs().max())

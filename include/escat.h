@@ -178,6 +178,15 @@ int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, const float 
                          const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
                          float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
                          int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream);
+/* The same without the slot / copy planning: entries in row order, copy A of the vector.  The chain then pays the LDS bank
+ * conflicts the plan would have avoided (measured at cfg2: P forward 0.25 instead of 0.20 ms) but the pack costs a
+ * tenth: for an operator that is used once (a DataLoader that yields fresh COO tensors every step,
+ * models/escgnn_data_classes.py:137-142), where the matching's milliseconds never pay back. */
+int escat_sell_pack_fill_unplanned(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *sign_bits,
+                                   int64_t n, int64_t nnz, const int32_t *part_ptr, int n_parts, int values_per_entry,
+                                   const escat_sell_dims *dims, void *workspace, size_t workspace_bytes,
+                                   float *val_out, uint32_t *lc_out, int32_t *lane_meta_out,
+                                   int32_t *slot_of_e, int32_t *lc_of_e, int8_t *ent_of_slot, void *stream);
 /* Values only, for an operator that shares pattern (rowptr / col), parts, dmax and layout with one packed before -- its
  * transpose on a symmetric pattern, or P and Q of one batch: pass the first pack's workspace and its ent_of_slot
  * (total_d * 64 bytes, optional output of escat_sell_pack_fill: which entry of its row each slot holds, -1 = padding);
@@ -185,6 +194,15 @@ int escat_sell_pack_fill(const int32_t *rowptr, const int32_t *col, const float 
 int escat_sell_pack_refill(const int32_t *rowptr, const float *val, int64_t n, const int32_t *part_ptr, int n_parts,
                            int values_per_entry, const escat_sell_dims *dims, const void *workspace,
                            size_t workspace_bytes, const int8_t *ent_of_slot, float *val_out, void *stream);
+
+/* The same for a sign-bit pack (values_per_entry 3 as |value| + sign bits: escat_sell.val_planes = 4) on the plan of a pack
+ * with the same pattern, parts, capacity and layout -- P's own pack, for the signed operator Pt of the factored vector
+ * operator: val_out ((total_d + 1) * 64 floats) = the magnitudes, lc_out (dims->lc_words) = the first pack's lc with the
+ * entries' sign bits in bits 11..13 of every 16-bit field.  lane_meta and pos_of_row are shared as they are. */
+int escat_sell_pack_refill_signed(const int32_t *rowptr, const float *mag, const int32_t *sign_bits, int64_t n,
+                                  const int32_t *part_ptr, int n_parts, const escat_sell_dims *dims, const void *workspace,
+                                  size_t workspace_bytes, const int8_t *ent_of_slot, const uint32_t *lc, float *val_out,
+                                  uint32_t *lc_out, void *stream);
 
 /* The half-valued form of a BSR-3 pack (escat_sell.half_val / .half_aux) from the canonical blocks and the plan of a pack
  * built before on the same pattern (workspace, ent_of_slot and lc of escat_sell_pack_fill, layout 1).  half_val_out:
@@ -448,10 +466,10 @@ int escat_rotate_frames_f32(const float *frames, const float *X, float *Y, int64
  * what escat_sell.frames + a val_planes = 3 / 4 operator take.  *max_err (device float, caller zeroes) receives the largest
  * |p_ij G_i S_ij G_j^T - Q_ij| over all block entries: the caller accepts the factorisation iff that is within its
  * tolerance (blocks rounded to fp16, the 'procrustes' alignment or any other operator leave it large). */
-size_t escat_recover_factored_lds_bytes(int max_part_rows);
+size_t escat_recover_factored_lds_bytes(int max_part_rows, int max_part_nnz);
 int escat_recover_factored(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
-                           const int32_t *part_ptr, int n_parts, int max_part_rows, float *frames_out, float *val3_out,
-                           float *max_err, void *stream);
+                           const int32_t *part_ptr, int n_parts, int max_part_rows, int max_part_nnz /* most entries of a part */,
+                           float *frames_out, float *val3_out, float *max_err, void *stream);
 
 /* host utility (no GPU): Jenkins lookup3 "hashlittle", the checksum of HDF5 version-2 object headers
  * (esc_gnn_amd/hdf5_min.py, the writer of the reference's operator layout). */
