@@ -37,15 +37,18 @@ extern "C" int escat_chain_csr_static_f32(const int32_t *rowptr, const int32_t *
                                           void *stream)
 {
     if (n < 0 || C < 1 || C > ESCAT_MAX_CHANNELS) return escat_fail(ESCAT_EINVAL, "n=%lld, C=%d: bad size", (long long)n, C);
-    const size_t need = escat_chain_workspace_bytes(n, C);
-    if (need > (size_t)ESCAT_STATIC_SCRATCH_BYTES)
-        return escat_fail(ESCAT_ERANGE, "escat_chain_csr_static_f32: n=%lld rows x C=%d channels need %zu B of scratch, the static "
-                                  "buffer holds %u B (use escat_chain_csr_f32 with a workspace)", (long long)n, C, need,
-                    (unsigned)ESCAT_STATIC_SCRATCH_BYTES);
     void *ws = nullptr;
     int rc = scratch_for_current_device(&ws); if (rc) return rc;
-    // every element of the ping-pong vectors is written by a step before the next one reads it: nothing to clear
-    return escat_chain_csr_f32(rowptr, col, val, n, nnz, X, C, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows, sell,
-                               ws, (size_t)ESCAT_STATIC_SCRATCH_BYTES, stream);
+    // Only the multi-launch path uses scratch (the register-resident and LDS-streaming paths keep their vectors in LDS):
+    // the size is checked where the path is chosen, inside escat_chain_csr_f32, against the array's size handed over as
+    // the workspace size -- a call that stays in LDS is never refused for its n.  Every element of the ping-pong vectors
+    // is written by a step before the next one reads it: nothing to clear.
+    rc = escat_chain_csr_f32(rowptr, col, val, n, nnz, X, C, T, events, n_events, F, OUT, part_ptr, n_parts, max_part_rows, sell,
+                             ws, (size_t)ESCAT_STATIC_SCRATCH_BYTES, stream);
+    if (rc == ESCAT_EWORKSPACE)
+        return escat_fail(ESCAT_ERANGE, "escat_chain_csr_static_f32: n=%lld rows x C=%d channels need %zu B of scratch on the "
+                                        "multi-launch path, the static buffer holds %u B (use escat_chain_csr_f32 with a workspace)",
+                          (long long)n, C, escat_chain_workspace_bytes(n, C), (unsigned)ESCAT_STATIC_SCRATCH_BYTES);
+    return rc;
 }
 

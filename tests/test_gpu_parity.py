@@ -60,12 +60,12 @@ def test_get_Batch_Wjxs_vs_goldens(sg, mode):
         assert W.is_cuda and W.dtype == torch.float32 and W.is_contiguous()
         _close(W, sg[f"P_{mode}_C{C}_W"])
         (W * torch.from_numpy(sg[f"P_{mode}_C{C}_gup"]).to(dev)).sum().backward()
-        _close(x.grad, sg[f"P_{mode}_C{C}_gx"], rtol=2e-5)
+        _close(x.grad, sg[f"P_{mode}_C{C}_gx"], rtol=1e-5)
     xv = torch.from_numpy(sg["x_v"]).to(dev).reshape(3 * N, 1).requires_grad_(True)
     W = get_Batch_Wjxs(xv, Q, **kw)
     _close(W, sg[f"Q_{mode}_W"])
     (W * torch.from_numpy(sg[f"Q_{mode}_gup"]).to(dev)).sum().backward()
-    _close(xv.grad, sg[f"Q_{mode}_gx"], rtol=2e-5)
+    _close(xv.grad, sg[f"Q_{mode}_gx"], rtol=1e-5)
 
 
 def test_perchannel_and_wide_C(sg):
@@ -88,7 +88,7 @@ def test_perchannel_and_wide_C(sg):
     xr = x.clone().requires_grad_(True)
     (co.ref_get_Batch_Wjxs(xr, P.cpu(), scales_type="dyadic", J=3) * gup).sum().backward()
     (W * gup.to(dev)).sum().backward()
-    _close(xg.grad, xr.grad.numpy(), rtol=2e-5)
+    _close(xg.grad, xr.grad.numpy(), rtol=1e-5)
 
 
 def test_vs_fp64_dense_reference(sg):
@@ -206,7 +206,7 @@ def test_vs_c_oracle_seeded(oracle_lib, B, n, k, J):
     gup = torch.randn(W.shape, generator=g)
     xg = xs.to(dev).requires_grad_(True)
     (get_Batch_Wjxs(xg, opP, J=J) * gup.to(dev)).sum().backward()
-    _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gup.numpy(), ev, plan.T), rtol=2e-5)
+    _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gup.numpy(), ev, plan.T), rtol=1e-5)
     xv = torch.from_numpy(b["pos"]).reshape(-1, 1)
     xvg = xv.to(dev).requires_grad_(True)
     Wq = get_Batch_Wjxs(xvg, opQ, J=J)
@@ -214,7 +214,7 @@ def test_vs_c_oracle_seeded(oracle_lib, B, n, k, J):
     _close(Wq, refq)
     gq = torch.randn(Wq.shape, generator=g)
     (Wq * gq.to(dev)).sum().backward()
-    _close(xvg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T), rtol=2e-5)
+    _close(xvg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T), rtol=1e-5)
 
 
 def test_all_three_chain_paths_agree(monkeypatch):
@@ -251,7 +251,7 @@ def test_all_three_chain_paths_agree(monkeypatch):
             Wq = get_Batch_Wjxs(xq, opQ, **kw)
             Wq.backward(gQ.to(dev))
             _close(W, refP); _close(Wq, refQ)
-            _close(xg.grad, refgP, rtol=2e-5); _close(xq.grad, refgQ, rtol=2e-5)
+            _close(xg.grad, refgP, rtol=1e-5); _close(xq.grad, refgQ, rtol=1e-5)
             outs[path] = (W.detach(), Wq.detach())
         # lane-group paths share lane mapping and summation order
         assert (outs["stream"][0] - outs["multi"][0]).abs().max() <= 1e-6 * outs["multi"][0].abs().max()
@@ -425,8 +425,8 @@ def test_persistent_pipeline_many_ragged_parts():
         Wq = get_Batch_Wjxs(xq, opQ, **kw); Wq.backward(gQ.to(dev))
         _close(W, co.c_chain_csr(b["rowptr"], b["col"], b["pval"], x.numpy(), ev, plan.T, plan.F))
         _close(Wq, co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.numpy().reshape(-1), ev, plan.T, plan.F))
-        _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T), rtol=2e-5)
-        _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=2e-5)
+        _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T), rtol=1e-5)
+        _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=1e-5)
 
 
 def test_operator_batch_views_of_a_stored_operator():
@@ -529,13 +529,13 @@ def test_locality_reordering_is_transparent(monkeypatch):
         _close(W, refP)
         gP = torch.randn(W.shape, generator=g)
         W.backward(gP.to(dev))
-        _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T), rtol=2e-5)
+        _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gP.numpy(), ev, plan.T), rtol=1e-5)
     xq = xv.to(dev).requires_grad_(True)
     Wq = get_Batch_Wjxs(xq, opQ, J=3)
     _close(Wq, refQ)
     gQ = torch.randn(Wq.shape, generator=g)
     Wq.backward(gQ.to(dev))
-    _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=2e-5)
+    _close(xq.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gQ.numpy(), ev, plan.T), rtol=1e-5)
 
 
 def test_scatter_fused_and_two_kernel_forms_agree(monkeypatch):
@@ -715,7 +715,7 @@ def test_cfg1_full_size_vs_c_oracle(oracle_lib):
             worst = max(worst, _within_fp32_noise_of_f64(W, r32, r64))
             gup = torch.randn(W.shape, generator=g)
             (W * gup.to(dev)).sum().backward()
-            _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gup.numpy(), ev, plan.T), rtol=2e-5)
+            _close(xg.grad, co.c_chain_csr_bwd(b["rowptr"], b["col"], b["pval"], gup.numpy(), ev, plan.T), rtol=1e-5)
         xv = pos.reshape(-1, 1)
         xvg = xv.to(dev).requires_grad_(True)
         Wq = get_Batch_Wjxs(xvg, opQ, **kw)
@@ -725,7 +725,7 @@ def test_cfg1_full_size_vs_c_oracle(oracle_lib):
         worst = max(worst, _within_fp32_noise_of_f64(Wq, q32, q64))
         gq = torch.randn(Wq.shape, generator=g)
         (Wq * gq.to(dev)).sum().backward()
-        _close(xvg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T), rtol=2e-5)
+        _close(xvg.grad, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], gq.numpy(), ev, plan.T), rtol=1e-5)
     print("worst |ours - f64| / |f32 oracle - f64| over bands:", worst)
 
 
