@@ -771,7 +771,7 @@ k_coo_sorted_to_csr(const long long *__restrict__ rows, const long long *__restr
     if (r < 0 || r >= n || c < 0 || c >= n) { atomicOr(bad, 1); return; }
     const long long pr = e ? rows[e - 1] : -1, pc = e ? cols[e - 1] : -1;
     if (e && !(r > pr || (r == pr && c > pc))) { atomicOr(bad, 1); return; }
-    if (pr >= n) return;
+    if (e && (pr < 0 || pr >= n)) return;               // entry e-1 flags itself; never index rowptr from its row
     col32[e] = (int)c;
     if (r != pr) fill_rowptr(rowptr, pr, r, e);
     if (e == nnz - 1) fill_rowptr(rowptr, r, n, nnz);

@@ -17,6 +17,7 @@ operator and cached on the tensor object); the products themselves never touch
 torch.
 """
 import os
+import weakref
 from typing import Optional
 import numpy as np
 import torch
@@ -48,7 +49,7 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
         return torch.zeros(1, dtype=torch.int32, device=dev), 0, 0
     key = (rowptr.data_ptr(), col.data_ptr(), rowptr._version, col._version, n, int(col.numel()), target)
     hit = _PARTS_CACHE.get("last")
-    if hit is not None and hit[0] == key and hit[1] is rowptr and hit[2] is col:
+    if hit is not None and hit[0] == key and hit[1]() is rowptr and hit[2]() is col:
         return hit[3]
     if rowptr.is_cuda and rowptr.dtype == torch.int32 and col.dtype == torch.int32:
         import ctypes
@@ -66,10 +67,12 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
         mx = ctypes.c_int32(0)
         k = lib.escat_merge_row_ranges(bounds.ctypes.data_as(ctypes.c_void_p), bounds.shape[0], target,
                                        out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(mx))
-        if k < 2:
+        if k < 0:
             _lib.check(int(k), "escat_merge_row_ranges")
+        if k < 2:
+            raise RuntimeError(f"escat_merge_row_ranges returned {int(k)} boundaries for n = {n} rows (needs >= 2)")
         res = (torch.from_numpy(out[:k].copy()).to(dev), int(k) - 1, int(mx.value))
-        _PARTS_CACHE["last"] = (key, rowptr, col, res)
+        _PARTS_CACHE["last"] = (key, weakref.ref(rowptr), weakref.ref(col), res)    # weak: the cache pins no pattern
         return res
     rp = rowptr.long()
     ar = torch.arange(n, device=dev)
@@ -190,7 +193,7 @@ def sell_swz_b(p):
     return (p & ~15) | ((p + 1 + ((p >> 5) % 15)) & 15)
 
 
-_PLAN_CACHE = {}         # (pattern identity, parts, dmax, layout) -> the last pack built on it (see Sell)
+_PLAN_CACHE = {}         # (pattern identity, parts, dmax, layout) -> weakref to the last pack built on it (see Sell)
 
 # Half-valued BSR-3 packs (include/escat.h: escat_sell.half_val): "auto" -- when every block value is exactly
 # representable as an IEEE half (operators that went through the reference's fp16 HDF5 storage) the pack holds halves
@@ -249,7 +252,11 @@ class Sell:
                form.part_ptr.data_ptr(), form.n_parts, form.max_part_rows, n, nnz, self.layout, str(dev))
         shared = None
         if not keep_plan and layout is None:
-            for cap_key, cand in _PLAN_CACHE.items():
+            for cap_key, cand_ref in list(_PLAN_CACHE.items()):
+                cand = cand_ref()
+                if cand is None:                                  # its operator is gone: so is the entry
+                    del _PLAN_CACHE[cap_key]
+                    continue
                 if cand.layout == self.layout and cand._ent is not None and cand.planned == (INGEST_POLICY != "single_use") \
                         and self._same_pattern(cand, form, cap_key[:-1] == key) \
                         and cand.dmax == self._capacity_for(V, cand):
@@ -329,7 +336,7 @@ class Sell:
         self.total_d = int(dims.total_d)
         if shared is None and self._ent is not None and layout is None:
             _PLAN_CACHE.clear()                          # one pattern at a time: batches come and go
-            _PLAN_CACHE[key + (self.dmax,)] = self
+            _PLAN_CACHE[key + (self.dmax,)] = weakref.ref(self)   # weak: a dropped operator frees its pack
 
     @staticmethod
     def _same_pattern(cand, form, same_key: bool) -> bool:

@@ -26,16 +26,32 @@ def _launch(world, tmp_path):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         out = str(tmp_path / f"w{world}_r{r}.pt")
         outs.append(out)
+        logf = open(str(tmp_path / f"w{world}_r{r}.log"), "w")     # a file, not a pipe: nobody reads while we poll
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out], env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    for p in procs:
-        try:
-            log, _ = p.communicate(timeout=240)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, log[-3000:]
+                                      stdout=logf, stderr=subprocess.STDOUT, text=True))
+        logf.close()
+    logs = [""] * world
+    try:
+        # wait for every rank before judging any: a rank that died leaves its siblings inside a collective
+        import time
+        deadline = time.monotonic() + 240
+        while any(p.poll() is None for p in procs):
+            if time.monotonic() > deadline or any(p.poll() not in (None, 0) for p in procs):
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:                                             # nothing of ours stays on the GPU past this point
+            if p.poll() is None:
+                p.kill()
+        for i, p in enumerate(procs):
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+            with open(str(tmp_path / f"w{world}_r{i}.log")) as f:
+                logs[i] = f.read()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} exit {p.returncode}\n" + "\n".join(l[-3000:] for l in logs)
     return [torch.load(o, weights_only=True) for o in outs]
 
 

@@ -212,6 +212,50 @@ def test_gpu_coo_ingest_matches_the_coalesced_structure():
     assert np.array_equal(cs2.val.cpu().numpy(), b["pval"])
 
 
+@pytest.mark.parametrize("blocks3", [0, 1])
+def test_gpu_coo_ingest_flags_out_of_range_rows_without_writing_outside_rowptr(blocks3):
+    """a negative or >= n row index sets *bad and nothing is written before or after rowptr (guard words on
+    both sides of the n + 1 entries), for the entry itself and for the entry after it (whose 'previous row' it is)."""
+    from esc_gnn_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    n = 40
+    s = 3 if blocks3 else 1
+    rows = np.repeat(np.arange(n), 2).astype(np.int64)
+    cols = np.stack([np.arange(n), (np.arange(n) + 1) % n], 1)
+    cols.sort(axis=1)
+    cols = cols.reshape(-1).astype(np.int64)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    GUARD = 0x5A5A5A5A
+
+    def run(r, c):
+        if blocks3:
+            a = np.arange(3)
+            r = ((3 * r)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1)
+            c = ((3 * c)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1)
+        rt, ct = torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev)
+        buf = torch.full((64 + n + 1 + 64,), GUARD, dtype=torch.int32, device=dev)
+        col32 = torch.full((64 + len(rows) + 64,), GUARD, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.escat_ingest_coo(vp(rt), vp(ct), len(r), s * n, blocks3, vp(buf[64:]), vp(col32[64:]), vp(bad),
+                                  ctypes.c_void_p(0))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert bool((buf[:64] == GUARD).all()) and bool((buf[64 + n + 1:] == GUARD).all())
+        assert bool((col32[:64] == GUARD).all()) and bool((col32[64 + len(rows):] == GUARD).all())
+        return int(bad.item()), buf[64:64 + n + 1].cpu().numpy()
+
+    ok, rp = run(rows, cols)
+    assert ok == 0 and np.array_equal(rp, 2 * np.arange(n + 1))
+    for at, value in ((10, -7), (10, -1), (11, n + 5), (0, -3), (len(rows) - 1, n), (len(rows) - 1, -2)):
+        r = rows.copy()
+        r[at] = value
+        assert run(r, cols)[0] == 1, (at, value)
+    r = rows.copy()
+    r[10], r[31] = -5, n + 2                                   # one negative and one >= n in the same tensor
+    assert run(r, cols)[0] == 1
+
+
 @pytest.mark.parametrize("graphs,n,k", [(3, 1500, 6), (2, 1100, 40), (1, 37, 5)])
 def test_bsr3_step_staged_vs_oracle(monkeypatch, graphs, n, k):
     """Multi-launch vector chain through the LDS-staged step kernel (k_bsr3_step_staged, the default) and through the

@@ -53,6 +53,59 @@ def test_static_scratch_entry_point_matches_workspace_entry_point(oracle_lib):
             assert np.abs(got.cpu().numpy()[..., f] - orc[..., f]).max() <= 1e-5 * np.abs(orc[..., f]).max()
 
 
+def test_static_entry_on_the_register_path_is_not_refused_for_its_size_and_allocates_nothing(oracle_lib):
+    """with part_ptr and a pack the chain stays in LDS and registers and uses no scratch, so a batch whose
+    multi-launch workspace would exceed the 8 MiB array (N = 600 k rows x C = 3) is served, bit-equal to the workspace
+    entry point; torch's allocator sees no allocation across the call (the library has no other allocator: grep
+    hipMalloc csrc/)."""
+    from esc_gnn_amd import _lib, synthetic, plan_chain, ScatterOperator
+    from esc_gnn_amd.pyg_utilities import _events_array
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    plan = plan_chain(scales_type="dyadic", J=3)
+    ev_arr = _events_array(plan.events)
+    ev_np = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    b = synthetic.ellipsoid_batch(1200, 500, 8, seed=3)
+    n, C = b["N"], 3
+    assert lib.escat_chain_workspace_bytes(n, C) > 8 << 20
+    t = lambda a: torch.from_numpy(a).to(dev)
+    op = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), n)
+    form = op.csr()
+    sell = form.sell()
+    assert sell is not None and form.n_parts > 0
+    half = getattr(sell, "half_val", None) is not None
+    ss = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(), sell.dmax, sell.n_slices,
+                        sell.slices_per_part, sell.val_planes, 0, 0, 0, 0, 0, 0, 0, 0, sell.layout, sell.pos_of_row.data_ptr(),
+                        sell.half_val.data_ptr() if half else 0, sell.half_aux.data_ptr() if half else 0)
+    sref = ctypes.cast(ctypes.pointer(ss), ctypes.c_void_p)
+    x = torch.randn(n, C, generator=torch.Generator().manual_seed(1)).to(dev)
+    vp = lambda a: ctypes.c_void_p(a.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for static in (False, True):
+        out = torch.full((n, C, plan.F), float("nan"), device=dev)
+        common = (vp(form.rowptr), vp(form.col), vp(form.val), n, form.nnz, vp(x), C, plan.T,
+                  ctypes.cast(ev_arr, ctypes.c_void_p), len(plan.events), plan.F, vp(out),
+                  vp(form.part_ptr), form.n_parts, form.max_part_rows, sref)
+        torch.cuda.synchronize()
+        before = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev))
+        if static:
+            rc = lib.escat_chain_csr_static_f32(*common, st)
+        else:
+            rc = lib.escat_chain_csr_f32(*common, ctypes.c_void_p(0), 0, st)
+        assert rc == 0, lib.escat_last_error()
+        torch.cuda.synchronize()
+        assert (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)) == before
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    sub = slice(0, 20 * 500)                                       # the oracle on the first 20 graphs (block-diagonal)
+    rp = b["rowptr"][:20 * 500 + 1]
+    orc = co.c_chain_csr(rp, b["col"][:rp[-1]], b["pval"][:rp[-1]], x[sub].cpu().numpy(), ev_np, plan.T, plan.F)
+    got = outs[1][sub].cpu().numpy()
+    for f in range(plan.F):
+        assert np.abs(got[..., f] - orc[..., f]).max() <= 1e-5 * np.abs(orc[..., f]).max()
+
+
 def test_static_scratch_rejects_oversize():
     from esc_gnn_amd import _lib
     from esc_gnn_amd.pyg_utilities import _events_array
