@@ -548,9 +548,16 @@ __device__ __forceinline__ void chain_epilogue_orders(const float *slab, float *
 template <class Op, int NT, bool BWD, bool ORD>     // ORD: forward with the orders epilogue (a separate instantiation:
 __global__ void __launch_bounds__(NT, (Op::MINW == 1 && NT == 256) ? 2 : Op::MINW)      // compiled into the plain kernel, its code costs the step loop registers)
 k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev sd, const float *__restrict__ IN,
-             float *__restrict__ RES, int T, EvTable tab, int F, int n_parts, int max_rows, int early)
+             float *__restrict__ RES, int T, EvTable tab, int F, int n_parts, int max_rows, int early, int stagger)
 {
     constexpr int C = Op::C, CP = Op::CP;
+    if (stagger) {                                // experiment: de-phase the workgroups that share a CU
+        const bool late = stagger > 0 ? (blockIdx.x >= (gridDim.x >> 1)) : (blockIdx.x & 1);
+        if (late) {
+            const unsigned long long t0 = wall_clock64(), dt = (unsigned long long)(stagger > 0 ? stagger : -stagger);
+            while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     constexpr bool POS = Op::POS;
     extern __shared__ __align__(16) float smem[];
     const int nv = 2 * sell_padR(max_rows) * CP;                 // two copies per vector, a multiple of 32 floats
@@ -756,9 +763,12 @@ static int launch_sell_k2(const int *ci, const float *v, int n_parts, int max_ro
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, NT, lds) != hipSuccess || per < 1) per = 1;
         cached_per_cu = per; cached_lds = lds; cached_dev = dev_now;
     }
-    const int64_t resident = (int64_t)cached_per_cu * escat_cu_count();
+    int per_cu = cached_per_cu, stagger = 0;
+    if (const char *e = getenv("ESCAT_DBG_PER_CU")) { const int v2 = atoi(e); if (v2 > 0 && v2 < per_cu) per_cu = v2; }
+    if (const char *e = getenv("ESCAT_DBG_STAGGER")) stagger = atoi(e);       // 10-ns ticks; < 0: odd workgroups instead of the second half
+    const int64_t resident = (int64_t)per_cu * escat_cu_count();
     const int grid = (int)(n_parts < resident ? n_parts : resident);           // persistent: one wave of workgroups
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ci, v, sd, IN, RES, T, tab, F, n_parts, max_rows, early);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ci, v, sd, IN, RES, T, tab, F, n_parts, max_rows, early, stagger);
     return ESCAT_OK;
 }
 

@@ -36,3 +36,24 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] == 1 and cb["value"] > 0
+
+
+def test_bench_two_rank_rehearsal_end_to_end():
+    """`bench.py --gpus 2` without a launcher around it starts its own two ranks before anything
+    touches the GPU; in rehearsal mode (ESCAT_BENCH_REHEARSAL=1: both ranks share this box's one card, gloo instead of
+    RCCL) the whole N > 1 path runs end to end -- shard per rank, barrier, max-over-ranks time, the collective's own
+    count of ranks -- and rank 0 alone prints the one JSON line."""
+    env = dict(os.environ, ESCAT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--graphs", "64", "--nodes", "128", "--k", "5",
+                        "--steps", "2", "--warmup", "1", "--no-cfg3", "--no-cpu-baseline", "--gen-workers", "1"],
+                       capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen_by_allreduce"] == 2 and d["collective_backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1
+    # weak scaling: 64 graphs per rank, value = all ranks' graphs / max-over-ranks time
+    assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]

@@ -768,6 +768,57 @@ def test_properties_at_full_cfg2_size():
     assert (S[..., 1 + F:] - Wx[..., iu[0]] * Wx[..., iu[1]]).abs().max() <= 1e-6 * S.abs().max()
 
 
+def test_full_cfg2_batch_sampled_graphs_vs_c_oracle(oracle_lib, monkeypatch):
+    """the FULL cfg2 batch (4096 graphs x 500 nodes, k = 10, dyadic J = 4) through the drop-in
+    call, forward and gradient, and 32 sampled graphs' rows against the C oracle run on just those diagonal blocks
+    (graphs are independent, so a block's rows depend on nothing outside it) -- both tracks, and the vector track on
+    both of its routes (the factored form recovered at ingest, and the BSR-3 register kernel)."""
+    from esc_gnn_amd import get_Batch_Wjxs, plan_chain, operators, ScatterOperator
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    from esc_gnn_amd import synthetic
+    dev = _dev()
+    B, n = 4096, 500
+    pos = torch.from_numpy(synthetic.ellipsoid_clouds(B, n, seed=457893).reshape(-1, 3)).to(dev)
+    gp = torch.arange(B + 1, dtype=torch.int32, device=dev) * n
+    b = build_PQ_batch(pos, gp, 10, {"kernel": "gaussian", "gaussian_eps": 0.05})
+    opP, opQ = b["P"], b["Q"]
+    plan = plan_chain(scales_type="dyadic", J=4)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    sample = np.unique(np.concatenate([[0, B - 1], np.random.default_rng(11).choice(B, 30, replace=False)]))
+    cp, cq = opP.csr(), opQ.bsr3()
+    rp_all = cp.rowptr.cpu().numpy()
+    assert np.array_equal(rp_all, cq.rowptr.cpu().numpy())
+    gen = torch.Generator(device=dev).manual_seed(5)
+
+    def blocks_of(g, col_t, val_t):
+        e0, e1 = int(rp_all[g * n]), int(rp_all[(g + 1) * n])
+        return (rp_all[g * n:(g + 1) * n + 1] - e0, col_t[e0:e1].cpu().numpy() - g * n, val_t[e0:e1].cpu().numpy())
+
+    def check(op, x, oracle_f, oracle_b, col_t, val_t, rows_per):
+        xg = x.clone().requires_grad_(True)
+        W = get_Batch_Wjxs(xg, op, scales_type="dyadic", J=4)
+        G = torch.randn(W.shape, device=dev, generator=gen)
+        (W * G).sum().backward()
+        for g in sample:
+            rp, cl, vl = blocks_of(int(g), col_t, val_t)
+            sl = slice(int(g) * n * rows_per, (int(g) + 1) * n * rows_per)
+            xin = x[sl].cpu().numpy()
+            _close(W[sl], oracle_f(rp, cl, vl, xin.reshape(-1) if rows_per == 3 else xin, ev, plan.T, plan.F))
+            _close(xg.grad[sl], oracle_b(rp, cl, vl, G[sl].cpu().numpy(), ev, plan.T), rtol=1e-5)
+
+    check(opP, torch.randn(B * n, 3, device=dev, generator=gen), co.c_chain_csr, co.c_chain_csr_bwd, cp.col, cp.val, 1)
+    xv = pos.reshape(-1, 1)
+    check(opQ, xv, co.c_chain_bsr3, co.c_chain_bsr3_bwd, cq.col, cq.val, 3)
+    from esc_gnn_amd.pyg_utilities import vector_route
+    route_default = type(vector_route(opQ, xv, plan.F, plan.events)).__name__
+    assert route_default == "FactoredVectorOperator"        # the builder's blocks: the factored form is recovered at ingest
+    monkeypatch.setattr(operators, "FACTOR_MODE", "0")
+    opQ2 = ScatterOperator.from_bsr3(cq.rowptr, cq.col, cq.val, B * n)
+    assert type(vector_route(opQ2, xv, plan.F, plan.events)).__name__ == "ScatterOperator"
+    check(opQ2, xv, co.c_chain_bsr3, co.c_chain_bsr3_bwd, cq.col, cq.val, 3)
+    print("vector track routes checked at full cfg2 size:", route_default, "and BSR-3 (ESCAT_Q_FACTOR=0)")
+
+
 def test_large_cloud_properties():
     """BASELINE cfg3 in kind (one connected cloud, k = 16, J = 6, vector track; 200 000 points so that the host kNN stays
     within seconds): the multi-launch path with the breadth-first relabelling, BSR-3 and factored form.  Properties:

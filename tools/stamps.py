@@ -67,5 +67,16 @@ for J in (0, 4):
     if half:
         ok = (s[:, 8] > 0) & (s[:, 9] > 0)
         print(f"   1 -> op loads issued {us(s[ok, 8] - s[ok, 1]).mean():6.2f} us; first-part input wait {us(s[ok, 9] - s[ok, 8]).mean():6.2f}; epilogue {us(s[ok, 2] - s[ok, 9]).mean():6.2f} us")
+    if "--timeline" in os.environ.get("STAMPS_OPTS", "") and J > 0:
+        # how many workgroups are inside their step phase (stamp 4 -> 6) at each microsecond of the launch: lockstep shows
+        # as a count that swings between 0 and all of them
+        t0 = s[:, 0][s[:, 0] > 0].min()
+        a = ((s[:, 4] - t0) // 100).astype(np.int64); bq = ((s[:, 6] - t0) // 100).astype(np.int64)
+        ok = (s[:, 4] > 0) & (s[:, 6] > 0)
+        n = int(bq[ok].max()) + 2
+        cnt = np.zeros(n, dtype=np.int64)
+        np.add.at(cnt, a[ok], 1); np.add.at(cnt, bq[ok] + 1, -1)
+        cnt = np.cumsum(cnt)
+        print("   workgroups in their step phase, per us:", " ".join(str(int(v)) for v in cnt[:-1]))
     ok = s[:, 7] > 0
     print(f"   part total (0 -> 7)                {us(s[ok, 7] - s[ok, 0]).mean():7.2f} us")
