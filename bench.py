@@ -176,7 +176,7 @@ def bench_fresh_coo(b, dev, t, args, xs, xv, reps=5):
     COO tensors every step (int64 indices, flagged un-coalesced; P row-major sorted, Q in block-emission order:
     models/escgnn_data_classes.py:137-142, process_pyg_data.py:839-857), forward only, both tracks, no gradient (how the
     reference trains: the scattering sits outside the autograd graph).  COO in -> bank out, everything included: ingest,
-    parts, packs, routing, the two chains.  Under both ingest policies (esc_gnn_amd.operators.INGEST_POLICY)."""
+    parts, packs, routing, the two chains.  Under the three ingest policies (esc_gnn_amd.operators.INGEST_POLICY)."""
     import torch
     from esc_gnn_amd import get_Batch_Wjxs, operators as _ops
     N = b["N"]
@@ -190,7 +190,7 @@ def bench_fresh_coo(b, dev, t, args, xs, xv, reps=5):
     Pv, Qv = t(b["pval"]), t(b["blk"]).reshape(-1)
     del rows, cols, rp
     res = {}
-    for policy in ("full", "single_use"):
+    for policy in ("auto", "full", "single_use"):
         _ops.INGEST_POLICY = policy
         ts = []
         for r in range(reps + 1):
@@ -209,10 +209,12 @@ def bench_fresh_coo(b, dev, t, args, xs, xv, reps=5):
             del P, Q, Ws, Wv
         ts.sort()
         res[policy] = {"ms_per_step": ts[len(ts) // 2], "min_ms": ts[0], "max_ms": ts[-1]}
-    _ops.INGEST_POLICY = "full"
+    _ops.INGEST_POLICY = "auto"
     res["what"] = ("fresh int64 COO P and Q every step -> get_Batch_Wjxs forward for both tracks (no gradient), wall clock with a "
-                   "synchronise at both ends, median of %d; 'full' = default ingest (matching slot plan, factored form recovered "
-                   "from Q's blocks), 'single_use' = ESCAT_INGEST=single_use (unplanned packs, no recovery)" % reps)
+                   "synchronise at both ends, median of %d; 'auto' = the default (a tensor object seen for the first time gets "
+                   "unplanned packs and no recovery, the full treatment from its second use on: every tensor here is new, so "
+                   "this is the single-use cost), 'full' = ESCAT_INGEST=full (matching slot plan, factored form recovered from "
+                   "Q's blocks, at once), 'single_use' = ESCAT_INGEST=single_use (never)" % reps)
     return res
 
 

@@ -64,6 +64,10 @@ SIGNATURES = {
     "escat_sell_pack_refill_signed": (ci, [vp, vp, vp, i64, vp, ci, vp, vp, sz, vp, vp, vp, vp, vp]),
     "escat_sell_pack_refill_half": (ci, [vp, vp, i64, vp, ci, vp, vp, sz, vp, vp, vp, vp, vp, vp]),
     "escat_ingest_coo": (ci, [vp, vp, i64, i64, ci, vp, vp, vp, vp]),
+    "escat_ingest_coo_cover": (ci, [vp, vp, i64, i64, vp, vp, vp, vp, vp]),
+    "escat_row_blocks_workspace_bytes": (sz, [i64]),
+    "escat_row_blocks": (i64, [vp, i64, i64, vp, sz, vp, i64, vp, vp]),
+    "escat_ingest_coo_like": (ci, [vp, vp, i64, i64, vp, vp, i64, vp, vp]),
     "escat_row_cover": (ci, [vp, vp, i64, vp, vp]),
     "escat_merge_row_ranges": (i64, [vp, i64, i64, vp, vp]),
     "escat_transpose_sym": (ci, [vp, vp, vp, i64, i64, ci, vp, vp, vp]),

@@ -15,6 +15,7 @@
 //      length), copy B swizzles inside 16-row groups (sell_swzB).  The owning thread then stores its new vector row at
 //      its own thread index: both copies' ds_write_b128 are conflict-free (8 consecutive lanes -> 8 distinct 16-B slots),
 //      where layout 0 stores to random rows (~2.6-way conflicts on every store of every step).
+#include <vector>
 #include "escat_dev.h"
 
 #define PACK_MAX_ROWS 512
@@ -761,9 +762,11 @@ __device__ __forceinline__ void fill_rowptr(int *__restrict__ rowptr, long long 
     for (long long q = prev_row + 1; q <= row; ++q) rowptr[q] = (int)e;
 }
 
+// delta (optional, n + 1 ints, zeroed): the row-cover marks of k_row_cover, made in the same pass -- a row's first entry
+// adds +1 at min(row, its column), its last entry -1 at max(row, its column) (a span of one row cancels itself)
 __global__ void __launch_bounds__(256)
 k_coo_sorted_to_csr(const long long *__restrict__ rows, const long long *__restrict__ cols, int64_t nnz, int64_t n,
-                    int *__restrict__ rowptr, int *__restrict__ col32, int *__restrict__ bad)
+                    int *__restrict__ rowptr, int *__restrict__ col32, int *__restrict__ bad, int *__restrict__ delta)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= nnz) return;
@@ -771,10 +774,19 @@ k_coo_sorted_to_csr(const long long *__restrict__ rows, const long long *__restr
     if (r < 0 || r >= n || c < 0 || c >= n) { atomicOr(bad, 1); return; }
     const long long pr = e ? rows[e - 1] : -1, pc = e ? cols[e - 1] : -1;
     if (e && !(r > pr || (r == pr && c > pc))) { atomicOr(bad, 1); return; }
-    if (e && (pr < 0 || pr >= n)) return;               // entry e-1 flags itself; never index rowptr from its row
+    if (e && (pr < 0 || pr >= n || pc < 0 || pc >= n)) return;     // entry e-1 flags itself; never index from its row
     col32[e] = (int)c;
-    if (r != pr) fill_rowptr(rowptr, pr, r, e);
-    if (e == nnz - 1) fill_rowptr(rowptr, r, n, nnz);
+    if (r != pr) {
+        fill_rowptr(rowptr, pr, r, e);
+        if (delta) {
+            atomicAdd(&delta[r < c ? r : c], 1);
+            if (e) atomicAdd(&delta[pr > pc ? pr : pc], -1);
+        }
+    }
+    if (e == nnz - 1) {
+        fill_rowptr(rowptr, r, n, nnz);
+        if (delta) atomicAdd(&delta[r > c ? r : c], -1);
+    }
 }
 
 // 63 lanes of a wave cover 7 blocks (one entry per lane: every load is one coalesced 504-byte access); the block's
@@ -821,8 +833,188 @@ extern "C" int escat_ingest_coo(const int64_t *rows, const int64_t *cols, int64_
                            (const long long *)rows, (const long long *)cols, nnzb, n / 3, rowptr, col32, bad);
     } else {
         hipLaunchKernelGGL(k_coo_sorted_to_csr, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, S(stream),
-                           (const long long *)rows, (const long long *)cols, nnz, n, rowptr, col32, bad);
+                           (const long long *)rows, (const long long *)cols, nnz, n, rowptr, col32, bad, (int *)nullptr);
     }
     CHECK_LAUNCH("escat_ingest_coo");
     return ESCAT_OK;
+}
+
+extern "C" int escat_ingest_coo_cover(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n,
+                                      int32_t *rowptr, int32_t *col32, int32_t *bad, int32_t *delta, void *stream)
+{
+    if (!rows || !cols || !rowptr || !col32 || !bad || !delta) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n <= 0 || nnz <= 0) return fail(ESCAT_EINVAL, "empty operator");
+    if (n >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return fail(ESCAT_ERANGE, "n or nnz >= 2^31 (int32 indices)");
+    hipError_t e = hipMemsetAsync(delta, 0, (size_t)(n + 1) * sizeof(int32_t), S(stream));
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync(delta): %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_coo_sorted_to_csr, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, S(stream),
+                       (const long long *)rows, (const long long *)cols, nnz, n, rowptr, col32, bad, delta);
+    CHECK_LAUNCH("escat_ingest_coo_cover");
+    return ESCAT_OK;
+}
+
+// Q of a batch whose P went through the ingest a moment ago: the blocks must be in block-emission order AND sit exactly on
+// the reference pattern (block b = entry b of the reference CSR).  Nothing is written but the flags: bit 0 = not in
+// block-emission order (as *bad above), bit 1 = in order but on another pattern.  No block depends on its neighbour, so
+// a wave keeps U trips of 7 blocks (two 8-byte loads per lane each) in flight.
+template <int U>
+__global__ void __launch_bounds__(256)
+k_coo_blocks_like(const long long *__restrict__ rows, const long long *__restrict__ cols, int64_t nnzb, int64_t nb,
+                  const int *__restrict__ ref_rowptr, const int *__restrict__ ref_col, int *__restrict__ flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int q = lane % 9, k = lane / 9;
+    long long r[U], c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t b = (wave * U + u) * 7 + k;
+        const bool live = lane < 63 && b < nnzb;
+        r[u] = -1; c[u] = -1;
+        if (live) { r[u] = __builtin_nontemporal_load(rows + 9 * b + q); c[u] = __builtin_nontemporal_load(cols + 9 * b + q); }
+    }
+    int f = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t b = (wave * U + u) * 7 + k;
+        const bool live = lane < 63 && b < nnzb;
+        const long long r0 = __shfl(r[u], lane - q, 64), c0 = __shfl(c[u], lane - q, 64);
+        if (!live) continue;
+        if (r[u] != r0 + q / 3 || c[u] != c0 + q % 3) { f |= 1; continue; }
+        if (q) continue;
+        if (r0 < 0 || c0 < 0 || r0 % 3 || c0 % 3 || r0 / 3 >= nb || c0 / 3 >= nb) { f |= 1; continue; }
+        const long long br = r0 / 3, bc = c0 / 3;
+        if (ref_col[b] != (int)bc || !((int64_t)ref_rowptr[br] <= b && b < (int64_t)ref_rowptr[br + 1])) f |= 2;
+    }
+    if (f) atomicOr(flags, f);
+}
+
+extern "C" int escat_ingest_coo_like(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n,
+                                     const int32_t *ref_rowptr, const int32_t *ref_col, int64_t ref_nnz, int32_t *flags, void *stream)
+{
+    if (!rows || !cols || !ref_rowptr || !ref_col || !flags) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n <= 0 || nnz <= 0 || n % 3 || nnz % 9) return fail(ESCAT_EINVAL, "a BSR-3 ingest needs n %% 3 == 0 and nnz %% 9 == 0 (both > 0)");
+    if (n >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return fail(ESCAT_ERANGE, "n or nnz >= 2^31 (int32 indices)");
+    if (ref_nnz != nnz / 9) return fail(ESCAT_EINVAL, "the reference pattern has %lld entries, the operator %lld blocks", (long long)ref_nnz, (long long)(nnz / 9));
+    constexpr int U = 4;
+    const int64_t nnzb = nnz / 9, waves = (nnzb + 7 * U - 1) / (7 * U);
+    hipLaunchKernelGGL(k_coo_blocks_like<U>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(stream),
+                       (const long long *)rows, (const long long *)cols, nnzb, n / 3, ref_rowptr, ref_col, flags);
+    CHECK_LAUNCH("escat_ingest_coo_like");
+    return ESCAT_OK;
+}
+
+// ------------------------------------------------------------------ the closed row ranges from the cover marks, in one call
+// delta: the +1 / -1 marks (k_row_cover, or k_coo_sorted_to_csr's delta).  Three small kernels -- block sums, the scan with
+// the cuts of every block compacted in place, the cuts of all blocks compacted -- then the (few thousand) cuts come to
+// the host, where the greedy merge runs (escat_merge_row_ranges).  delta is overwritten.
+#define COVER_ROWS 2048           // rows per workgroup: 256 threads x 8
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int *sh, int *total)
+{
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int x = v;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(x, m, 64); if (lane >= m) x += o; }
+    if (lane == 63) sh[w] = x;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += sh[i];
+    *total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(256)
+k_cover_sums(const int *__restrict__ delta, int64_t n, int *__restrict__ bsum)
+{
+    __shared__ int sh[4];
+    const int64_t r0 = (int64_t)blockIdx.x * COVER_ROWS + threadIdx.x * 8;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (r0 + i < n) s += delta[r0 + i];
+    int tot;
+    (void)block_exclusive_scan_256(s, sh, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256)
+k_cover_cuts(int *__restrict__ delta, int64_t n, const int *__restrict__ bsum, int *__restrict__ bcnt)
+{
+    __shared__ int sh[4];
+    int carry = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) carry += bsum[b];
+    int tot;
+    (void)block_exclusive_scan_256(carry, sh, &tot);
+    carry = tot;                                   // marks of all rows before this block
+    const int64_t r0 = (int64_t)blockIdx.x * COVER_ROWS + threadIdx.x * 8;
+    int d[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i] = r0 + i < n ? delta[r0 + i] : 0; s += d[i]; }
+    int run = carry + block_exclusive_scan_256(s, sh, &tot);
+    int cut[8], nc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { run += d[i]; cut[i] = (r0 + i < n - 1 && run == 0) ? 1 : 0; nc += cut[i]; }
+    int pos = block_exclusive_scan_256(nc, sh, &tot);      // (its barriers also order the loads above before the stores below)
+    int *list = delta + (int64_t)blockIdx.x * COVER_ROWS;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (cut[i]) list[pos++] = (int)(r0 + i + 1);
+    if (threadIdx.x == 0) bcnt[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256)
+k_cover_compact(const int *__restrict__ delta, const int *__restrict__ bcnt, int nblk, int *__restrict__ cuts, int *__restrict__ total)
+{
+    __shared__ int sh[4];
+    int off = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) off += bcnt[b];
+    int tot;
+    (void)block_exclusive_scan_256(off, sh, &tot);
+    const int cnt = bcnt[blockIdx.x];
+    const int *list = delta + (int64_t)blockIdx.x * COVER_ROWS;
+    for (int i = threadIdx.x; i < cnt; i += 256) cuts[tot + i] = list[i];
+    if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) *total = tot + cnt;
+}
+
+extern "C" size_t escat_row_blocks_workspace_bytes(int64_t n)
+{
+    const int64_t nblk = (n + COVER_ROWS - 1) / COVER_ROWS;
+    return (size_t)(2 * nblk + 4 + n) * sizeof(int32_t);
+}
+
+extern "C" int64_t escat_row_blocks(int32_t *delta, int64_t n, int64_t target, void *workspace, size_t workspace_bytes,
+                                    int32_t *out_host, int64_t out_cap, int32_t *max_rows, void *stream)
+{
+    if (!delta || !workspace || !out_host || !max_rows) return fail(ESCAT_EINVAL, "NULL pointer");
+    if (n <= 0 || n >= ((int64_t)1 << 31)) return fail(ESCAT_EINVAL, "n = %lld", (long long)n);
+    if (workspace_bytes < escat_row_blocks_workspace_bytes(n)) return fail(ESCAT_EWORKSPACE, "escat_row_blocks: workspace too small");
+    const int nblk = (int)((n + COVER_ROWS - 1) / COVER_ROWS);
+    int *bsum = (int *)workspace, *bcnt = bsum + nblk, *total = bcnt + nblk, *cuts = total + 4;
+    hipLaunchKernelGGL(k_cover_sums, dim3(nblk), dim3(256), 0, S(stream), delta, n, bsum);
+    hipLaunchKernelGGL(k_cover_cuts, dim3(nblk), dim3(256), 0, S(stream), delta, n, bsum, bcnt);
+    hipLaunchKernelGGL(k_cover_compact, dim3(nblk), dim3(256), 0, S(stream), delta, bcnt, nblk, cuts, total);
+    CHECK_LAUNCH("escat_row_blocks");
+    // count and (optimistically) the first cuts in one copy; the rest only if there are more
+    static thread_local std::vector<int64_t> bounds;
+    static thread_local std::vector<int32_t> stage;
+    const int64_t first = 1 << 14;
+    stage.resize((size_t)(4 + first));
+    const int64_t have = n < first ? n : first;
+    hipError_t e = hipMemcpyAsync(stage.data(), total, (size_t)(4 + have) * sizeof(int32_t), hipMemcpyDeviceToHost, S(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "escat_row_blocks: %s", hipGetErrorString(e));
+    const int64_t nc = stage[0];
+    if (nc < 0 || nc >= n) return fail(ESCAT_ELAUNCH, "escat_row_blocks: %lld cuts for %lld rows", (long long)nc, (long long)n);
+    if (nc > have) {
+        stage.resize((size_t)(4 + nc));
+        e = hipMemcpyAsync(stage.data() + 4 + have, cuts + have, (size_t)(nc - have) * sizeof(int32_t), hipMemcpyDeviceToHost, S(stream));
+        if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
+        if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "escat_row_blocks: %s", hipGetErrorString(e));
+    }
+    if (nc + 2 > out_cap) return fail(ESCAT_ERANGE, "escat_row_blocks: %lld boundaries, room for %lld", (long long)(nc + 2), (long long)out_cap);
+    bounds.resize((size_t)(nc + 2));
+    bounds[0] = 0;
+    for (int64_t i = 0; i < nc; ++i) bounds[(size_t)i + 1] = stage[(size_t)(4 + i)];
+    bounds[(size_t)nc + 1] = n;
+    return escat_merge_row_ranges(bounds.data(), nc + 2, target, out_host, max_rows);
 }

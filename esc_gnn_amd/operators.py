@@ -49,8 +49,16 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
         return torch.zeros(1, dtype=torch.int32, device=dev), 0, 0
     key = (rowptr.data_ptr(), col.data_ptr(), rowptr._version, col._version, n, int(col.numel()), target)
     hit = _PARTS_CACHE.get("last")
-    if hit is not None and hit[0] == key and hit[1]() is rowptr and hit[2]() is col:
-        return hit[3]
+    if hit is not None:
+        crp, ccl = hit[1](), hit[2]()
+        if hit[0] == key and crp is rowptr and ccl is col:
+            return hit[3]
+        # the same pattern in other tensors: P and Q of one batch arrive as separate COO tensors whose canonical patterns
+        # (scalar rows of P = block rows of Q) are equal element for element; two compares instead of the scan
+        if crp is not None and ccl is not None and hit[0][4:] == key[4:] and crp.device == dev and crp.dtype == rowptr.dtype \
+                and ccl.dtype == col.dtype and crp._version == hit[0][2] and ccl._version == hit[0][3] \
+                and bool(torch.equal(ccl, col)) and bool(torch.equal(crp, rowptr)):
+            return hit[3]
     if rowptr.is_cuda and rowptr.dtype == torch.int32 and col.dtype == torch.int32:
         import ctypes
         from . import _lib
@@ -101,6 +109,32 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
     out = np.unique(np.asarray(out, dtype=np.int64))
     max_rows = int(np.diff(out).max())
     return torch.from_numpy(out.astype(np.int32)).to(dev), len(out) - 1, max_rows
+
+
+def _row_blocks_from_marks(delta: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, n: int, target: int):
+    """_closed_row_ranges for a pattern whose row-cover marks are already there (escat_ingest_coo_cover): one library
+    call (three small kernels, one copy of the cuts to the host, the merge there) and the upload of the part
+    boundaries.  The result enters the parts cache, where Q of the same batch finds it."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    dev = delta.device
+    ws = torch.empty(lib.escat_row_blocks_workspace_bytes(n) // 4, dtype=torch.int32, device=dev)
+    cap = n + 2                                          # (never touched beyond the boundaries written)
+    out = np.empty(cap, dtype=np.int32)
+    mx = ctypes.c_int32(0)
+    with torch.cuda.device(dev):
+        k = lib.escat_row_blocks(ctypes.c_void_p(delta.data_ptr()), n, target, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4,
+                                 out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(mx),
+                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if k < 0:
+        _lib.check(int(k), "escat_row_blocks")
+    if k < 2:
+        raise RuntimeError(f"escat_row_blocks returned {int(k)} boundaries for n = {n} rows (needs >= 2)")
+    res = (torch.from_numpy(out[:k].copy()).to(dev), int(k) - 1, int(mx.value))
+    key = (rowptr.data_ptr(), col.data_ptr(), rowptr._version, col._version, n, int(col.numel()), target)
+    _PARTS_CACHE["last"] = (key, weakref.ref(rowptr), weakref.ref(col), res)
+    return res
 
 
 REORDER_MIN_ROWS = 16384     # a connected block this large cannot live in LDS: its x gather goes to L2/HBM every step
@@ -208,12 +242,23 @@ HALF_MAX_DMAX = 20
 FACTOR_MODE = os.environ.get("ESCAT_Q_FACTOR", "auto")
 FACTOR_TOL = 1e-6
 
-# How much to invest in an operator at ingest.  "full" (default): everything that makes the chains fast -- the matching
-# slot plan of the SELL pack, the factored form of Q -- a few milliseconds per 4096-graph batch that pay back after a
-# handful of steps (stores, cached batches, repeated epochs).  "single_use": for callers that hand over FRESH tensors
-# every step (the reference's DataLoader, models/escgnn_data_classes.py:137-142): unplanned packs, no recovery of the
-# factored form; the half-valued pack is still taken when the values are exact in fp16 (it costs less than the fp32 one).
-INGEST_POLICY = os.environ.get("ESCAT_INGEST", "full")
+# How much to invest in an operator at ingest.
+#   "full": everything that makes the chains fast -- the matching slot plan of the SELL pack, the factored form of Q -- a
+#     few milliseconds per 4096-graph batch that pay back after a handful of steps (stores, cached batches, epochs).
+#   "single_use": unplanned packs, no recovery of the factored form; the half-valued pack is still taken when the values
+#     are exact in fp16 (it costs less than the fp32 one).
+#   "auto" (default): operators built explicitly (from_csr / from_bsr3 / from_torch / stores) are "full"; a torch sparse
+#     tensor handed straight to get_Batch_Wjxs / scatter -- what the reference's DataLoader yields, fresh tensors every
+#     step (models/escgnn_data_classes.py:137-142) -- starts "single_use" and is promoted to "full" the SECOND time the
+#     same tensor object comes back (ScatterOperator.promote): a batch seen once never pays for a plan it cannot use, a
+#     batch that is reused pays once, at its second use.
+INGEST_POLICY = os.environ.get("ESCAT_INGEST", "auto")
+
+
+def _policy_of(form) -> str:
+    """the effective policy ("full" / "single_use") for a canonical form"""
+    p = getattr(form, "policy", None) or INGEST_POLICY
+    return "full" if p == "auto" else p
 
 
 class Sell:
@@ -257,7 +302,7 @@ class Sell:
                 if cand is None:                                  # its operator is gone: so is the entry
                     del _PLAN_CACHE[cap_key]
                     continue
-                if cand.layout == self.layout and cand._ent is not None and cand.planned == (INGEST_POLICY != "single_use") \
+                if cand.layout == self.layout and cand._ent is not None and cand.planned == (_policy_of(form) != "single_use") \
                         and self._same_pattern(cand, form, cap_key[:-1] == key) \
                         and cand.dmax == self._capacity_for(V, cand):
                     shared = cand
@@ -306,7 +351,7 @@ class Sell:
                 else:
                     src_val, bits = form.val, None
                 null = ctypes.c_void_p(0)
-                self.planned = INGEST_POLICY != "single_use"
+                self.planned = _policy_of(form) != "single_use"
                 fill = lib.escat_sell_pack_fill if self.planned else lib.escat_sell_pack_fill_unplanned
                 _lib.check(fill(vp(form.rowptr), vp(form.col), vp(src_val),
                                                     vp(bits) if bits is not None else null, n, nnz,
@@ -435,8 +480,8 @@ class SellGlobal:
 
 
 class _Csr:
-    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "max_row_nnz", "_sell", "_sell_g",
-                 "_signed")
+    __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "_max_row_nnz", "_sell", "_sell_g",
+                 "_signed", "policy")
 
     def __init__(self, rowptr, col, val, n, parts=None):
         self.rowptr, self.col, self.val, self.n = rowptr, col, val, n
@@ -444,10 +489,17 @@ class _Csr:
         if parts is None:
             parts = _closed_row_ranges(rowptr, col, n, PART_TARGET_ROWS)
         self.part_ptr, self.n_parts, self.max_part_rows = parts
-        self.max_row_nnz = int((rowptr[1:] - rowptr[:-1]).max()) if n > 0 else 0
+        self._max_row_nnz = None        # diagnostic, on demand (a reduction + a host round trip)
         self._sell = None
         self._sell_g = None
         self._signed = None
+        self.policy = None              # None: the module's INGEST_POLICY; set by the owning ScatterOperator
+
+    @property
+    def max_row_nnz(self) -> int:
+        if self._max_row_nnz is None:
+            self._max_row_nnz = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if self.n > 0 else 0
+        return self._max_row_nnz
 
     def signed_pack(self):
         """per-channel values (nnz, 3) that differ in sign only (the signed operator of a factored vector operator):
@@ -502,6 +554,24 @@ class ScatterOperator:
         self.row_inv = None             # old -> new (y = y'[row_inv])
         self._factored = None           # see factored(): FactoredVectorOperator, or False once recovery was refused
         self.factor_err = None          # relative reconstruction error of the recovery (diagnostic)
+        self.policy = None              # None: the module's INGEST_POLICY ("auto" = full); as_operator sets "single_use"
+
+    def _stamp(self, form):
+        if form is not None and self.policy is not None:
+            form.policy = self.policy
+        return form
+
+    def promote(self):
+        """a single-use operator that came back: from now on it gets the full treatment (planned packs, factored form)"""
+        if self.policy != "single_use":
+            return
+        self.policy = "full"
+        for f in (self._csr, self._csr_t, self._bsr, self._bsr_t):
+            if f is not None:
+                f.policy = "full"
+                if f._sell is not None and not f._sell.planned:
+                    f._sell = None      # rebuilt, planned, at the next chain
+        self._factored = None
 
     def _parts_for(self, unit: int):
         """explicit parts for a form whose rows are `unit` scalar rows each (None: find the closed row ranges)"""
@@ -611,15 +681,42 @@ class ScatterOperator:
             gp = torch.as_tensor(graph_ptr, device=dev).to(torch.int64)
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            tries = ([1] if (n % 3 == 0 and nnz % 9 == 0) else []) + [0]
+            blocks_possible = n % 3 == 0 and nnz % 9 == 0
+            if blocks_possible and gp is None:
+                # Q of a batch whose P was ingested a moment ago: one pass checks the block-emission order AND that the
+                # blocks sit on P's pattern; P's rowptr / col / parts are then Q's (and the packs share P's plan by identity)
+                hit = _PARTS_CACHE.get("last")
+                crp, ccl = (hit[1](), hit[2]()) if hit is not None else (None, None)
+                if crp is not None and ccl is not None and crp.device == dev and crp.dtype == torch.int32 and ccl.dtype == torch.int32 \
+                        and crp.numel() == n // 3 + 1 and ccl.numel() == nnz // 9 and hit[0][6] == PART_TARGET_ROWS \
+                        and crp._version == hit[0][2] and ccl._version == hit[0][3]:
+                    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+                    _lib.check(lib.escat_ingest_coo_like(vp(r), vp(c), nnz, n, vp(crp), vp(ccl), nnz // 9, vp(flags), st),
+                               "escat_ingest_coo_like")
+                    f = int(flags.item())
+                    if f == 0:
+                        op = ScatterOperator(n, dev)
+                        op._bsr = _Csr(crp, ccl, val.to(torch.float32).reshape(-1, 3, 3).contiguous(), n // 3, hit[3])
+                        op.bsr_fill = 1.0
+                        op._reorder_if_large()
+                        return op
+                    if f & 1:
+                        blocks_possible = False          # not block-emission order at all
+            tries = ([1] if blocks_possible else []) + [0]
             for blocks3 in tries:
                 rows_out = n // 3 if blocks3 else n
                 ne = nnz // 9 if blocks3 else nnz
                 rowptr = torch.empty(rows_out + 1, dtype=torch.int32, device=dev)
                 col32 = torch.empty(ne, dtype=torch.int32, device=dev)
                 bad = torch.zeros(1, dtype=torch.int32, device=dev)
-                _lib.check(lib.escat_ingest_coo(vp(r), vp(c), nnz, n, blocks3, vp(rowptr), vp(col32), vp(bad), st),
-                           "escat_ingest_coo")
+                delta = None
+                if blocks3 or gp is not None:
+                    _lib.check(lib.escat_ingest_coo(vp(r), vp(c), nnz, n, blocks3, vp(rowptr), vp(col32), vp(bad), st),
+                               "escat_ingest_coo")
+                else:                                    # the row-cover marks in the same pass (parts below)
+                    delta = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                    _lib.check(lib.escat_ingest_coo_cover(vp(r), vp(c), nnz, n, vp(rowptr), vp(col32), vp(bad), vp(delta), st),
+                               "escat_ingest_coo_cover")
                 if int(bad.item()):
                     continue
                 op = ScatterOperator(n, dev)
@@ -630,7 +727,8 @@ class ScatterOperator:
                     op._bsr = _Csr(rowptr, col32, v32.reshape(-1, 3, 3).contiguous(), n // 3, parts)
                     op.bsr_fill = 1.0
                 else:
-                    op._csr = _Csr(rowptr, col32, v32.contiguous(), n, op._parts_for(1))
+                    parts = op._parts_for(1) if gp is not None else _row_blocks_from_marks(delta, rowptr, col32, n, PART_TARGET_ROWS)
+                    op._csr = _Csr(rowptr, col32, v32.contiguous(), n, parts)
                     if n % 3 == 0:
                         op._maybe_bsr3_from_csr()
                 op._reorder_if_large()
@@ -742,12 +840,12 @@ class ScatterOperator:
                 order = torch.argsort(key)
                 rows, cols, vals = rows.reshape(-1)[order], cols.reshape(-1)[order], b.val.reshape(-1)[order]
                 self._csr = _Csr(_rowptr(rows, self.n), cols.to(torch.int32), vals.contiguous(), self.n)
-        return self._csr
+        return self._stamp(self._csr)
 
     def bsr3(self) -> _Csr:
         if self._bsr is None:
             raise RuntimeError("operator has no BSR-3 form")
-        return self._bsr
+        return self._stamp(self._bsr)
 
     def _transpose_sym(self, c: _Csr):
         """A^T on A's own pattern when the pattern is symmetric (always, for P / Q of undirected graphs): one HIP kernel
@@ -787,7 +885,7 @@ class ScatterOperator:
         if self._factored is None:
             self._factored = False
             b = self._bsr
-            if b is not None and FACTOR_MODE != "0" and INGEST_POLICY != "single_use" and b.val.is_cuda and b.nnz > 0 and 0 < b.max_part_rows <= SELL_MAX_PART_ROWS \
+            if b is not None and FACTOR_MODE != "0" and _policy_of(self._stamp(b)) != "single_use" and b.val.is_cuda and b.nnz > 0 and 0 < b.max_part_rows <= SELL_MAX_PART_ROWS \
                     and self.row_perm is None and not self.values_look_fp16():
                 import ctypes
                 from . import _lib
@@ -826,7 +924,7 @@ class ScatterOperator:
             # a block-diagonal operator and its transpose have the same diagonal blocks: same parts
             self._csr_t = _Csr(_rowptr(c.col.long()[order], c.n), rows[order].to(torch.int32),
                                c.val[order].contiguous(), c.n, (c.part_ptr, c.n_parts, c.max_part_rows))
-        return self._csr_t
+        return self._stamp(self._csr_t)
 
     def bsr3_t(self) -> _Csr:
         if self._bsr_t is None:
@@ -838,7 +936,7 @@ class ScatterOperator:
             order = torch.argsort(b.col.long() * b.n + rows)
             self._bsr_t = _Csr(_rowptr(b.col.long()[order], b.n), rows[order].to(torch.int32),
                                b.val[order].transpose(1, 2).contiguous(), b.n, (b.part_ptr, b.n_parts, b.max_part_rows))
-        return self._bsr_t
+        return self._stamp(self._bsr_t)
 
 
     # ---------------------------------------------------------------- batches drawn from a stored operator
@@ -999,9 +1097,13 @@ def as_operator(P_sparse):
         op = None
     if op is None:
         op = ScatterOperator.from_torch(P_sparse)
+        if INGEST_POLICY == "auto":
+            op.policy = "single_use"        # seen once so far: see INGEST_POLICY
         try:
             P_sparse._escat_operator = op
             P_sparse._escat_versions = ver
         except Exception:
             pass
+    elif op.policy == "single_use" and INGEST_POLICY == "auto":
+        op.promote()                        # the same tensor object again: worth a plan
     return op

@@ -231,6 +231,26 @@ int escat_ingest_coo(const int64_t *rows, const int64_t *cols, int64_t nnz, int6
 int escat_row_cover(const int32_t *rowptr, const int32_t *col, int64_t n, int32_t *delta, void *stream);
 int64_t escat_merge_row_ranges(const int64_t *bounds, int64_t nb, int64_t target, int32_t *out, int32_t *max_rows);
 
+/* The same ingest for a tensor handed over ONCE (a DataLoader's fresh batch, models/escgnn_data_classes.py:137-142), where
+ * every launch and host round trip shows (round 3):
+ * escat_ingest_coo_cover = escat_ingest_coo(blocks3 = 0) that also leaves escat_row_cover's marks in delta (n + 1 ints,
+ *   zeroed here) -- the pattern is read once for both;
+ * escat_row_blocks: from those marks to the parts, in one call -- prefix sum, cuts and their compaction as three small
+ *   kernels, the cuts copied to the host, escat_merge_row_ranges there.  Synchronises the stream.  delta is overwritten;
+ *   workspace (device) of escat_row_blocks_workspace_bytes(n); out_host: room for out_cap boundaries (HOST).  Returns
+ *   the number of boundaries or a negative error code;
+ * escat_ingest_coo_like: Q in block-emission order whose blocks sit exactly on a pattern already ingested (P of the same
+ *   batch: ref_rowptr (n/3 + 1), ref_col (ref_nnz) = its canonical CSR).  Writes nothing but *flags (device, caller
+ *   zeroes): 0 = same pattern, the caller reuses P's rowptr / col / parts / pack plan; bit 0 = not in block-emission
+ *   order; bit 1 = another pattern (then escat_ingest_coo decides). */
+int escat_ingest_coo_cover(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n,
+                           int32_t *rowptr, int32_t *col32, int32_t *bad, int32_t *delta, void *stream);
+size_t escat_row_blocks_workspace_bytes(int64_t n);
+int64_t escat_row_blocks(int32_t *delta, int64_t n, int64_t target, void *workspace, size_t workspace_bytes,
+                         int32_t *out_host, int64_t out_cap, int32_t *max_rows, void *stream);
+int escat_ingest_coo_like(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n,
+                          const int32_t *ref_rowptr, const int32_t *ref_col, int64_t ref_nnz, int32_t *flags, void *stream);
+
 /* The transposed operator for the backward entry points when the PATTERN is symmetric (undirected graphs: P and Q of
  * process_pyg_data always are): A^T then lives on A's own rowptr / col, and val_t[(j,i)] = val[(i,j)] (3x3 blocks
  * transposed for values_per_entry = 9).  *not_symmetric (device, caller zeroes) is set to 1 if some (i,j) has no (j,i):

@@ -79,7 +79,18 @@ def test_drop_in_takes_the_factored_kernel_by_itself_and_matches_the_reference(r
     n3 = int(r3g["N3"])
     Q = _coo(r3g["Q_indices"], r3g["Q_values_f32"], n3, dev)
     xv = torch.from_numpy(r3g["x_v"]).to(dev)
-    assert isinstance(vector_route(as_operator(Q), xv.reshape(-1, 1), 6), FactoredVectorOperator)
+    # default ingest policy ("auto"): the first time a tensor object is seen it gets the single-use treatment (BSR-3
+    # kernel on an unplanned pack: a DataLoader's batch comes once); when the same tensor comes back it is promoted and the
+    # factored form is found.  Both routes must meet the goldens.
+    x1 = xv.reshape(-1, 1).clone().requires_grad_(True)
+    W1 = get_Batch_Wjxs(x1, Q, scales_type="dyadic", J=4)
+    op1 = as_operator.__globals__["ScatterOperator"] and getattr(Q, "_escat_operator")
+    assert op1.policy == "single_use" and op1._factored is False and not op1.bsr3().sell().planned
+    _close(W1, r3g["f32_dyadic_J4_W"])
+    W1.backward(torch.from_numpy(r3g["f32_dyadic_J4_gup"]).to(dev))
+    _close(x1.grad.reshape(-1, 1), r3g["f32_dyadic_J4_gx"].reshape(-1, 1))
+    assert isinstance(vector_route(as_operator(Q), xv.reshape(-1, 1), 6), FactoredVectorOperator)     # second use: promoted
+    assert as_operator(Q) is op1 and op1.policy == "full"
     modes = {"dyadic_J4": dict(scales_type="dyadic", J=4),
              "custom_0_16": dict(scales_type="custom", diffusion_scales=torch.tensor([0, 1, 2, 4, 6, 8, 16])),
              "custom_1_2_4": dict(scales_type="custom", diffusion_scales=torch.tensor([1, 2, 4])),

@@ -256,6 +256,99 @@ def test_gpu_coo_ingest_flags_out_of_range_rows_without_writing_outside_rowptr(b
     assert run(r, cols)[0] == 1
 
 
+def _coo_of(b):
+    N = b["N"]
+    rows = np.repeat(np.arange(N), np.diff(b["rowptr"])).astype(np.int64)
+    cols = b["col"].astype(np.int64)
+    a = np.arange(3)
+    qr = ((3 * rows)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1)
+    qc = ((3 * cols)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1)
+    return rows, cols, qr, qc
+
+
+def test_single_pass_ingest_cover_and_row_blocks_match_the_scan():
+    """round 3: escat_ingest_coo_cover (CSR + row-cover marks in one pass) and escat_row_blocks (marks -> parts in one
+    call) give the rowptr / col of escat_ingest_coo and the parts of the cummax / cummin formulation (CPU path of
+    _closed_row_ranges), on ragged graphs and several merge targets."""
+    from esc_gnn_amd import _lib, synthetic
+    from esc_gnn_amd.operators import _closed_row_ranges, _row_blocks_from_marks, _PARTS_CACHE
+    from tests.test_gpu_parity import _concat_batches
+    lib = _lib.load()
+    dev = _dev()
+    b = _concat_batches([synthetic.ellipsoid_batch(5, 37, 4, seed=1), synthetic.ellipsoid_batch(3, 300, 8, seed=2),
+                         synthetic.ellipsoid_batch(40, 12, 3, seed=3), synthetic.ellipsoid_batch(2, 2100, 6, seed=4)])
+    rows, cols, _, _ = _coo_of(b)
+    N, nnz = b["N"], b["nnz"]
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    rt, ct = torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)
+    for target in (1, 64, 256, 100000):
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        col32 = torch.empty(nnz, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        delta = torch.full((N + 1,), 12345, dtype=torch.int32, device=dev)          # the call zeroes it
+        assert lib.escat_ingest_coo_cover(vp(rt), vp(ct), nnz, N, vp(rowptr), vp(col32), vp(bad), vp(delta), ctypes.c_void_p(0)) == 0
+        assert int(bad.item()) == 0
+        assert np.array_equal(rowptr.cpu().numpy(), b["rowptr"]) and np.array_equal(col32.cpu().numpy(), b["col"])
+        _PARTS_CACHE.clear()
+        got = _row_blocks_from_marks(delta, rowptr, col32, N, target)
+        want = _closed_row_ranges(torch.from_numpy(b["rowptr"]), torch.from_numpy(b["col"]), N, target)
+        assert got[1:] == want[1:] and torch.equal(got[0].cpu(), want[0]), target
+        assert _PARTS_CACHE["last"][3] is got                                       # where Q of the batch finds it
+
+
+def test_like_ingest_recognises_the_pattern_of_the_batch():
+    """round 3: escat_ingest_coo_like -- Q in block-emission order on P's pattern gives flags 0; blocks out of order or
+    with a broken 3x3 layout set bit 0; a well-formed Q on another pattern sets bit 1 (and only that).  Through
+    from_torch, Q then SHARES P's rowptr / col / parts tensors, and a Q that arrives alone takes the general route to
+    the same canonical form."""
+    from esc_gnn_amd import _lib, synthetic, ScatterOperator
+    from esc_gnn_amd.operators import _PARTS_CACHE, _PLAN_CACHE
+    lib = _lib.load()
+    dev = _dev()
+    b = synthetic.ellipsoid_batch(7, 110, 6, seed=8)
+    rows, cols, qr, qc = _coo_of(b)
+    N, nnz = b["N"], b["nnz"]
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    rp, cl = torch.from_numpy(b["rowptr"]).to(dev), torch.from_numpy(b["col"]).to(dev)
+
+    def flags_of(r, c, ref_rp=rp, ref_cl=cl):
+        rt, ct = torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev)
+        fl = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert lib.escat_ingest_coo_like(vp(rt), vp(ct), len(r), 3 * N, vp(ref_rp), vp(ref_cl), ref_cl.numel(), vp(fl), ctypes.c_void_p(0)) == 0
+        return int(fl.item())
+
+    assert flags_of(qr, qc) == 0
+    sw = np.arange(nnz); sw[[5, 6]] = [6, 5]                                      # two blocks swapped: well-formed, other pattern
+    swap = (sw[:, None] * 9 + np.arange(9)[None, :]).reshape(-1)
+    assert flags_of(qr[swap], qc[swap]) == 2
+    r2 = qr.copy(); r2[9 * 40 + 4] += 1                                           # a block that is not 3x3 row-major
+    assert flags_of(r2, qc) & 1
+    c2 = qc.copy(); c2[9 * 17:9 * 18] += 3                                        # a block moved one block column to the right
+    f = flags_of(qr, c2)
+    assert f == 2 or (b["col"][17] + 1 >= N and f & 1)
+    cl2 = cl.clone(); cl2[100] = (cl2[100] + 1) % N                               # the reference differs in one column
+    assert flags_of(qr, qc, rp, cl2) == 2
+    r3 = qr.copy(); r3[-9:] = -3                                                  # out of range
+    assert flags_of(r3, qc) & 1
+    # NULL / size errors come back as codes
+    fl = torch.zeros(1, dtype=torch.int32, device=dev)
+    rt = torch.from_numpy(qr).to(dev)
+    assert lib.escat_ingest_coo_like(vp(rt), vp(rt), len(qr), 3 * N, vp(rp), vp(cl), nnz - 1, vp(fl), ctypes.c_void_p(0)) == -1
+
+    P = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cols])), torch.from_numpy(b["pval"]), (N, N)).to(dev)
+    Q = torch.sparse_coo_tensor(torch.from_numpy(np.stack([qr, qc])), torch.from_numpy(b["blk"].reshape(-1)), (3 * N, 3 * N)).to(dev)
+    _PARTS_CACHE.clear(); _PLAN_CACHE.clear()
+    opQ_alone = ScatterOperator.from_torch(Q)
+    _PARTS_CACHE.clear(); _PLAN_CACHE.clear()
+    opP = ScatterOperator.from_torch(P)
+    opQ = ScatterOperator.from_torch(Q)
+    cp, cq, ca = opP.csr(), opQ.bsr3(), opQ_alone.bsr3()
+    assert cq.rowptr is cp.rowptr and cq.col is cp.col and cq.part_ptr is cp.part_ptr
+    assert ca.rowptr is not cp.rowptr and torch.equal(ca.rowptr, cq.rowptr) and torch.equal(ca.col, cq.col)
+    assert torch.equal(ca.val, cq.val) and torch.equal(ca.part_ptr, cq.part_ptr) and ca.n_parts == cq.n_parts
+    assert cq.sell().lc.data_ptr() == cp.sell().lc.data_ptr() or cq.sell().dmax != cp.sell().dmax      # one plan for both
+
+
 @pytest.mark.parametrize("graphs,n,k", [(3, 1500, 6), (2, 1100, 40), (1, 37, 5)])
 def test_bsr3_step_staged_vs_oracle(monkeypatch, graphs, n, k):
     """Multi-launch vector chain through the LDS-staged step kernel (k_bsr3_step_staged, the default) and through the

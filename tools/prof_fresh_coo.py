@@ -21,6 +21,7 @@ if os.environ.get("ESCAT_FP16_VALUES"):
 xs = t(b["pos"]); xv = t(b["pos"]).reshape(-1, 1)
 ts = []
 for r in range(6):
+    operators._PLAN_CACHE.clear(); operators._PARTS_CACHE.clear()      # as bench.py: the next batch has other graphs
     torch.cuda.synchronize(); t0 = time.perf_counter()
     P = torch.sparse_coo_tensor(Pi, Pv, (N, N), check_invariants=False)
     Q = torch.sparse_coo_tensor(Qi, Qv, (3 * N, 3 * N), check_invariants=False)
