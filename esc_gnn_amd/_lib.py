@@ -32,13 +32,13 @@ class EscatSell(ctypes.Structure):
                 ("part_list", ctypes.c_void_p), ("part_row0", ctypes.c_void_p), ("n_list", ctypes.c_int32),
                 ("orders", ctypes.c_int32), ("frames", ctypes.c_void_p),
                 ("layout", ctypes.c_int32), ("pos_of_row", ctypes.c_void_p),
-                ("half_val", ctypes.c_void_p), ("half_aux", ctypes.c_void_p)]
+                ("half_val", ctypes.c_void_p), ("half_aux", ctypes.c_void_p), ("ent_of_slot", ctypes.c_void_p)]
 
 
 class EscatSellDims(ctypes.Structure):
     _fields_ = [("dmax", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("slices_per_part", ctypes.c_int32),
                 ("layout", ctypes.c_int32), ("total_d", ctypes.c_int64), ("total_p", ctypes.c_int64),
-                ("val_floats", ctypes.c_int64), ("lc_words", ctypes.c_int64)]
+                ("val_floats", ctypes.c_int64), ("lc_words", ctypes.c_int64), ("row_len_hist", ctypes.c_int32 * 34)]
 
 
 # name -> (restype, argtypes); every symbol include/escat.h declares
@@ -66,7 +66,7 @@ SIGNATURES = {
     "escat_ingest_coo": (ci, [vp, vp, i64, i64, ci, vp, vp, vp, vp]),
     "escat_ingest_coo_cover": (ci, [vp, vp, i64, i64, vp, vp, vp, vp, vp]),
     "escat_row_blocks_workspace_bytes": (sz, [i64]),
-    "escat_row_blocks": (i64, [vp, i64, i64, vp, sz, vp, i64, vp, vp]),
+    "escat_row_blocks": (i64, [vp, i64, i64, vp, sz, vp, i64, vp, vp, vp, vp]),
     "escat_ingest_coo_like": (ci, [vp, vp, i64, i64, vp, vp, i64, vp, vp]),
     "escat_row_cover": (ci, [vp, vp, i64, vp, vp]),
     "escat_merge_row_ranges": (i64, [vp, i64, i64, vp, vp]),

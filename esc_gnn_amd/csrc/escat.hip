@@ -1082,7 +1082,9 @@ static int chain_path_override()
 
 static int sell_to_dev(const escat_sell *sell, SellDev *sd)
 {
-    if ((!sell->val && !sell->half_val) || !sell->lc || !sell->lane_meta) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
+    if ((!sell->val && !sell->half_val && !sell->ent_of_slot) || !sell->lc || !sell->lane_meta) return fail(ESCAT_EINVAL, "escat_sell has a NULL member");
+    sd->ent = (!sell->val && !sell->half_val) ? (const signed char *)sell->ent_of_slot : nullptr;
+    sd->rowptr = nullptr;
     if (((uintptr_t)sell->val & 15) != 0) return fail(ESCAT_EINVAL, "escat_sell.val must be 16-byte aligned");
     if ((sell->half_val != nullptr) != (sell->half_aux != nullptr)) return fail(ESCAT_EINVAL, "escat_sell.half_val and half_aux go together");
     sd->half_val = sell->half_val; sd->half_aux = sell->half_aux;
@@ -1184,6 +1186,7 @@ static int chain_csr(const int32_t *rowptr, const int32_t *col, const float *val
                 SellDev sd;
                 rc = sell_to_dev(sell, &sd); if (rc) return rc;
                 if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
+                if (!sd.val) return fail(ESCAT_EINVAL, "escat_sell.val is NULL (CSR packs have no half-valued or direct form)");
                 rc = launch_csr_sell<BWD>(C, max_part_rows, col, val, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
             } else if (sell && (sell->part_list || sell->orders || sell->val_planes >= 3))
                 return fail(ESCAT_EINVAL, LIST_NEEDS_REG);
@@ -1275,11 +1278,12 @@ static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *bl
             SellDev sd;
             rc = sell_to_dev(sell, &sd); if (rc) return rc;
             if (BWD && sd.orders) return fail(ESCAT_EINVAL, "escat_sell.orders must be 0 for a backward entry point");
+            sd.rowptr = rowptr;
             // half-valued pack (escat_sell_bsr3h.hip) when given and instantiated for the capacity; ESCAT_Q_HALF=0: ignore it
             static const bool no_half = getenv("ESCAT_Q_HALF") && !strcmp(getenv("ESCAT_Q_HALF"), "0");
             if (sd.half_val && sd.dmax <= 20 && !(no_half && sd.val))
                 rc = escat_launch_bsr3h_sell(BWD, max_part_rows, col, blk, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
-            else if (!sd.val) return fail(ESCAT_EINVAL, "escat_sell.val is NULL and the half-valued pack cannot be used (dmax=%d)", sd.dmax);
+            else if (!sd.val && !sd.ent) return fail(ESCAT_EINVAL, "escat_sell.val is NULL and the half-valued pack cannot be used (dmax=%d)", sd.dmax);
             else
             rc = escat_launch_bsr3_sell(BWD, max_part_rows, col, blk, sd.part_list ? sell->n_list : n_parts, sd, IN, RES, T, tab, F, st);
             if (rc) return rc;

@@ -131,7 +131,8 @@ struct SellDev {
     int layout;                                   // 0: LDS rows = local rows; 1: LDS rows = owner positions (see sell_swzB)
     const int *pos_of_row;                        // layout 1: global row -> position (for the streamed tails)
     const void *half_val; const unsigned *half_aux;   // half-valued BSR-3 pack (escat_sell_bsr3h.hip), NULL otherwise
-};
+    const signed char *ent; const int *rowptr;        // "direct" BSR-3 (no value pack): the plan's entry of every slot, the
+};                                                    // canonical row pointers (escat_sell.ent_of_slot)
 
 #define SLOT_GROUP 4      // granule of the packed LDS-row pairs (slots are padded to it)
 #define GATHER_AHEAD 3     // LDS gathers in flight ahead of the FMAs

@@ -21,37 +21,80 @@
 #define PACK_MAX_ROWS 512
 
 // ------------------------------------------------------------------ histogram of row lengths (clamped to 33)
+// (nearly every row of a kNN graph has one of three or four lengths: LDS atomics on those bins serialise; the lanes that
+// share a length are counted with one ballot instead)
 __global__ void __launch_bounds__(256)
 k_pack_hist(const int *__restrict__ rowptr, int64_t n, unsigned *__restrict__ hist)
 {
     __shared__ unsigned h[34];
     if (threadIdx.x < 34) h[threadIdx.x] = 0;
     __syncthreads();
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
-        const int d = rowptr[r + 1] - rowptr[r];
-        atomicAdd(&h[d < 33 ? d : 33], 1u);
+    const int lane = threadIdx.x & 63;
+    for (int64_t r0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); r0 < n; r0 += (int64_t)gridDim.x * 256) {
+        const int64_t r = r0 + lane;
+        int d = -1;
+        if (r < n) { d = rowptr[r + 1] - rowptr[r]; d = d < 33 ? d : 33; }
+        unsigned long long todo = __ballot(d >= 0);
+        while (todo) {                                           // one round per distinct length in the wave
+            const int dl = __builtin_amdgcn_readlane(d, __builtin_ctzll(todo));
+            const unsigned long long same = __ballot(d == dl);
+            if (lane == __builtin_ctzll(todo)) atomicAdd(&h[dl], (unsigned)__builtin_popcountll(same));
+            todo &= ~same;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 34 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
+// capacity: the smallest instantiated one that leaves at most 5e-5 of the rows a streamed tail; on the
+// device, so that the plan needs one host round trip instead of two.  hist[40] = dmax.
+__global__ void k_pack_pick_dmax(unsigned *__restrict__ hist, int64_t n, int values_per_entry)
+{
+    if (threadIdx.x) return;
+    const int caps1[] = {8, 16, 20, 24, 32}, caps3[] = {8, 16, 20, 24, 24}, caps9[] = {8, 12, 16, 20, 22};
+    const int *caps = values_per_entry == 1 ? caps1 : values_per_entry == 3 ? caps3 : caps9;
+    const long long allowed = (long long)(5e-5 * (double)n);
+    int dmax = caps[4];
+    for (int i = 4; i >= 0; --i) {
+        long long longer = 0;
+        for (int d = caps[i] + 1; d < 34; ++d) longer += hist[d];
+        if (longer <= allowed) dmax = caps[i];
+    }
+    hist[40] = (unsigned)dmax;
+}
+
 // ------------------------------------------------------------------ per part: order rows by length, slice widths
 // perm[(part*nsl)*64 + k] = local row at lane position k (-1: none); pos_of_row[gs + r] = k; w[part*nsl + s] = width.
+// Stable counting sort on the (few) distinct lengths: a ballot per key value gives every row its rank among the rows of
+// its wave with the same key, per-wave counts in LDS give the rest.
 __global__ void __launch_bounds__(PACK_MAX_ROWS)
-k_pack_order(const int *__restrict__ rowptr, const int *__restrict__ part_ptr, int dmax, int nsl,
+k_pack_order(const int *__restrict__ rowptr, const int *__restrict__ part_ptr, const unsigned *__restrict__ dmax_p, int nsl,
              int *__restrict__ perm, int *__restrict__ pos_of_row, int *__restrict__ w)
 {
-    __shared__ unsigned char key[PACK_MAX_ROWS];
+    __shared__ int cnt[PACK_MAX_ROWS / 64][34], base[34];
+    const int dmax = (int)*dmax_p;
     const int part = blockIdx.x, gs = part_ptr[part], rows = part_ptr[part + 1] - gs;
-    const int r = threadIdx.x;
-    int d = 0;
-    if (r < rows) { d = rowptr[gs + r + 1] - rowptr[gs + r]; d = d < dmax ? d : dmax; key[r] = (unsigned char)(dmax - d); }
+    const int r = threadIdx.x, lane = r & 63, wv = r >> 6;
+    int d = 0, key = -1;
+    if (r < rows) { d = rowptr[gs + r + 1] - rowptr[gs + r]; d = d < dmax ? d : dmax; key = dmax - d; }
+    int mine = 0;
+    for (int k = 0; k <= dmax; ++k) {
+        const unsigned long long m = __ballot(key == k);
+        if (lane == 0) cnt[wv][k] = __builtin_popcountll(m);
+        if (key == k) mine = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (r <= dmax) {                               // rows of all waves with a smaller key
+        int b = 0;
+        for (int k = 0; k < r; ++k)
+            for (int q = 0; q < PACK_MAX_ROWS / 64; ++q) b += cnt[q][k];
+        base[r] = b;
+    }
     __syncthreads();
     int *pp = perm + (int64_t)part * nsl * 64;
     if (r < rows) {
-        const int k = key[r];
-        int rank = 0;                              // stable: ties keep row order (torch.argsort(..., stable=True) of round 1)
-        for (int q = 0; q < rows; ++q) { const int kq = key[q]; rank += (kq < k) || (kq == k && q < r); }
+        int rank = base[key] + mine;
+        for (int q = 0; q < wv; ++q) rank += cnt[q][key];
         pp[rank] = r;
         pos_of_row[gs + r] = rank;
         if ((rank & 63) == 0) w[part * nsl + (rank >> 6)] = d;      // descending: a slice's first lane has its longest row
@@ -61,26 +104,36 @@ k_pack_order(const int *__restrict__ rowptr, const int *__restrict__ part_ptr, i
 }
 
 // ------------------------------------------------------------------ exclusive scans over the slices (one workgroup)
+// tiles of 4096 slices: four consecutive slices per thread (coalesced), a block scan per tile, the carry between tiles
 __global__ void __launch_bounds__(1024)
 k_pack_scan(const int *__restrict__ w, int n_slices, int *__restrict__ doff, int *__restrict__ poff)
 {
-    __shared__ long long sd[1024], sp[1024];
-    const int t = threadIdx.x;
-    const int per = (n_slices + 1023) / 1024;
-    const int a = t * per, b = a + per < n_slices ? a + per : n_slices;
-    long long d = 0, p = 0;
-    for (int s = a; s < b; ++s) { d += w[s]; p += ((w[s] + 3) / 4) * 2; }
-    sd[t] = d; sp[t] = p;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const long long vd = t >= off ? sd[t - off] : 0, vp = t >= off ? sp[t - off] : 0;
+    __shared__ int wd[16], wp[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int carry_d = 0, carry_p = 0;
+    for (int s0 = 0; s0 < n_slices; s0 += 4096) {
+        const int a = s0 + 4 * t;
+        int v[4], q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a + i < n_slices ? w[a + i] : 0; q[i] = ((v[i] + 3) / 4) * 2; }
+        const int sd_ = v[0] + v[1] + v[2] + v[3], sp_ = q[0] + q[1] + q[2] + q[3];
+        int xd = sd_, xp = sp_;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int od = __shfl_up(xd, m, 64), op = __shfl_up(xp, m, 64);
+            if (lane >= m) { xd += od; xp += op; }
+        }
+        if (lane == 63) { wd[wv] = xd; wp[wv] = xp; }
         __syncthreads();
-        sd[t] += vd; sp[t] += vp;
+        int bd = carry_d, bp = carry_p, td = 0, tp = 0;
+        for (int i = 0; i < 16; ++i) { if (i < wv) { bd += wd[i]; bp += wp[i]; } td += wd[i]; tp += wp[i]; }
         __syncthreads();
+        int d = bd + xd - sd_, p = bp + xp - sp_;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (a + i < n_slices) { doff[a + i] = d; poff[a + i] = p; d += v[i]; p += q[i]; }
+        carry_d += td; carry_p += tp;
     }
-    d = sd[t] - d; p = sp[t] - p;                 // exclusive prefix of this thread's chunk
-    for (int s = a; s < b; ++s) { doff[s] = (int)d; poff[s] = (int)p; d += w[s]; p += ((w[s] + 3) / 4) * 2; }
-    if (t == 1023) { doff[n_slices] = (int)sd[1023]; poff[n_slices] = (int)sp[1023]; }
+    if (t == 0) { doff[n_slices] = carry_d; poff[n_slices] = carry_p; }
 }
 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // a 16-byte load that is only dword-aligned
@@ -498,28 +551,19 @@ extern "C" int escat_sell_pack_plan(const int32_t *rowptr, int64_t n, const int3
     if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
     int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_pack_hist, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, n, ws.hist);
-    unsigned hist[34];
-    e = hipMemcpyAsync(hist, ws.hist, sizeof(hist), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "row-length histogram: %s", hipGetErrorString(e));
-    // capacity: the smallest instantiated one that leaves at most 5e-5 of the rows a streamed tail
-    static const int caps1[] = {8, 16, 20, 24, 32}, caps3[] = {8, 16, 20, 24}, caps9[] = {8, 12, 16, 20, 22};
-    const int *caps = values_per_entry == 1 ? caps1 : values_per_entry == 3 ? caps3 : caps9;
-    const int ncap = values_per_entry == 3 ? 4 : 5;
-    const int64_t allowed = (int64_t)(5e-5 * (double)n);
-    int dmax = caps[ncap - 1];
-    for (int i = 0; i < ncap; ++i) {
-        int64_t longer = 0;
-        for (int d = caps[i] + 1; d < 34; ++d) longer += hist[d];
-        if (longer <= allowed) { dmax = caps[i]; break; }
-    }
-    hipLaunchKernelGGL(k_pack_order, dim3(n_parts), dim3(PACK_MAX_ROWS), 0, st, rowptr, part_ptr, dmax, nsl, ws.perm, ws.pos, ws.w);
+    hipLaunchKernelGGL(k_pack_pick_dmax, dim3(1), dim3(64), 0, st, ws.hist, n, values_per_entry);
+    hipLaunchKernelGGL(k_pack_order, dim3(n_parts), dim3(PACK_MAX_ROWS), 0, st, rowptr, part_ptr, ws.hist + 40, nsl, ws.perm, ws.pos, ws.w);
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, ws.w, (int)ns, ws.doff, ws.poff);
+    // one round trip: the histogram + the capacity picked on the device, and the two totals
+    unsigned hist[41];
     int tot[2];
-    e = hipMemcpyAsync(&tot[0], ws.doff + ns, sizeof(int), hipMemcpyDeviceToHost, st);
+    e = hipMemcpyAsync(hist, ws.hist, sizeof(hist), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&tot[0], ws.doff + ns, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&tot[1], ws.poff + ns, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "slice offsets: %s", hipGetErrorString(e));
+    const int dmax = (int)hist[40];
+    for (int i = 0; i < 34; ++i) dims->row_len_hist[i] = (int32_t)hist[i];
     CHECK_LAUNCH("escat_sell_pack_plan");
     dims->dmax = dmax; dims->n_slices = (int32_t)ns; dims->slices_per_part = nsl; dims->layout = layout;
     dims->total_d = tot[0]; dims->total_p = tot[1];
@@ -963,7 +1007,8 @@ k_cover_cuts(int *__restrict__ delta, int64_t n, const int *__restrict__ bsum, i
 }
 
 __global__ void __launch_bounds__(256)
-k_cover_compact(const int *__restrict__ delta, const int *__restrict__ bcnt, int nblk, int *__restrict__ cuts, int *__restrict__ total)
+k_cover_compact(const int *__restrict__ delta, const int *__restrict__ bcnt, int nblk, int *__restrict__ cuts, int *__restrict__ total,
+                const int *__restrict__ flag_in)
 {
     __shared__ int sh[4];
     int off = 0;
@@ -973,7 +1018,7 @@ k_cover_compact(const int *__restrict__ delta, const int *__restrict__ bcnt, int
     const int cnt = bcnt[blockIdx.x];
     const int *list = delta + (int64_t)blockIdx.x * COVER_ROWS;
     for (int i = threadIdx.x; i < cnt; i += 256) cuts[tot + i] = list[i];
-    if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) *total = tot + cnt;
+    if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) { total[0] = tot + cnt; total[1] = flag_in ? *flag_in : 0; }
 }
 
 extern "C" size_t escat_row_blocks_workspace_bytes(int64_t n)
@@ -983,7 +1028,8 @@ extern "C" size_t escat_row_blocks_workspace_bytes(int64_t n)
 }
 
 extern "C" int64_t escat_row_blocks(int32_t *delta, int64_t n, int64_t target, void *workspace, size_t workspace_bytes,
-                                    int32_t *out_host, int64_t out_cap, int32_t *max_rows, void *stream)
+                                    int32_t *out_host, int64_t out_cap, int32_t *max_rows, const int32_t *flag_dev, int32_t *flag_host,
+                                    void *stream)
 {
     if (!delta || !workspace || !out_host || !max_rows) return fail(ESCAT_EINVAL, "NULL pointer");
     if (n <= 0 || n >= ((int64_t)1 << 31)) return fail(ESCAT_EINVAL, "n = %lld", (long long)n);
@@ -992,7 +1038,7 @@ extern "C" int64_t escat_row_blocks(int32_t *delta, int64_t n, int64_t target, v
     int *bsum = (int *)workspace, *bcnt = bsum + nblk, *total = bcnt + nblk, *cuts = total + 4;
     hipLaunchKernelGGL(k_cover_sums, dim3(nblk), dim3(256), 0, S(stream), delta, n, bsum);
     hipLaunchKernelGGL(k_cover_cuts, dim3(nblk), dim3(256), 0, S(stream), delta, n, bsum, bcnt);
-    hipLaunchKernelGGL(k_cover_compact, dim3(nblk), dim3(256), 0, S(stream), delta, bcnt, nblk, cuts, total);
+    hipLaunchKernelGGL(k_cover_compact, dim3(nblk), dim3(256), 0, S(stream), delta, bcnt, nblk, cuts, total, flag_dev);
     CHECK_LAUNCH("escat_row_blocks");
     // count and (optimistically) the first cuts in one copy; the rest only if there are more
     static thread_local std::vector<int64_t> bounds;
@@ -1004,6 +1050,8 @@ extern "C" int64_t escat_row_blocks(int32_t *delta, int64_t n, int64_t target, v
     if (e == hipSuccess) e = hipStreamSynchronize(S(stream));
     if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "escat_row_blocks: %s", hipGetErrorString(e));
     const int64_t nc = stage[0];
+    if (flag_host) *flag_host = stage[1];
+    if (flag_dev && stage[1]) return 0;           // the marks are those of a tensor the ingest refused: nothing to merge
     if (nc < 0 || nc >= n) return fail(ESCAT_ELAUNCH, "escat_row_blocks: %lld cuts for %lld rows", (long long)nc, (long long)n);
     if (nc > have) {
         stage.resize((size_t)(4 + nc));

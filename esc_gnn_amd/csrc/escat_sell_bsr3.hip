@@ -5,6 +5,10 @@ template <int DMAX, bool BWD>
 static int launch_bsr3_sell_d(int max_rows, const int *ci, const float *v, int n_parts, const SellDev &sd, const float *IN,
                               float *RES, int T, const EvTable &tab, int F, hipStream_t st)
 {
+    if (sd.ent) {           // direct: no value pack (escat_sell.ent_of_slot)
+        if (max_rows <= 256) return launch_sell_k<OpBsr3<DMAX, true>, 256, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+        return launch_sell_k<OpBsr3<DMAX, true>, 512, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
+    }
     if (max_rows <= 256) return launch_sell_k<OpBsr3<DMAX>, 256, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
     return launch_sell_k<OpBsr3<DMAX>, 512, BWD>(ci, v, n_parts, max_rows, sd, IN, RES, T, tab, F, st);
 }

@@ -55,7 +55,10 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) { return (unsigned)
 //   load(sd, doff, poff, w, lane)  issue the (coalesced) loads of this lane's slots
 //   gather(xa, w, acc)          acc += sum over slots of value * x[LDS row]   (one step)
 //   tail(...)                   entries beyond dmax, streamed
-template <int DMAX> struct OpBsr3 {
+struct __attribute__((packed, aligned(4))) f4u_k { float x, y, z, w; };    // a 16-byte load that is only dword-aligned
+
+template <int DMAX, bool DIRECT_ = false> struct OpBsr3 {
+    static constexpr bool DIRECT = DIRECT_;       // no value pack: the blocks come straight from the canonical array (escat_sell.ent_of_slot)
     static constexpr bool FRAMES = false;
     static constexpr bool POS = true;             // takes layout-1 packs (LDS rows = owner positions)
     static constexpr int C = 3, CP = 4, MINW = 1;
@@ -75,6 +78,31 @@ template <int DMAX> struct OpBsr3 {
     // the width.  Written with a branch per slot ("load if d < w, else keep / zero") the compiler merges loaded and
     // kept values through register copies that need the data -- a vmcnt(0) after every slot, i.e. twenty serial HBM
     // round trips per part instead of one burst (measured with tools/stamps.py: 16 us vs the ~9 us the bytes take).
+    // DIRECT: slot d of this lane holds entry e0 + ent[(doff + d) * 64 + lane] of the canonical (nnz, 3, 3) array `blk`
+    // (e0 = first entry of the lane's row); a padded slot (ent < 0, or a lane without a row) reads block 0 and is zeroed.
+    // 36 contiguous bytes per block and lane: strided over the lanes, every byte of every line used once.
+    __device__ __forceinline__ void load_direct(const SellDev &sd, const float *__restrict__ blk, int doff, int poff, int w, int lane, int e0)
+    {
+        const signed char *eb = sd.ent + (int64_t)doff * 64 + lane;
+        const int wl = w > 0 ? w - 1 : 0;
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+        int j[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) j[d] = w > 0 ? (int)eb[(d < wl ? d : wl) * 64] : -1;
+#pragma unroll
+        for (int j2 = 0; j2 < (DMAX + 1) / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            const float *bb = blk + (int64_t)(j[d] < 0 ? 0 : e0 + j[d]) * 9;
+            const f4u_k lo = *reinterpret_cast<const f4u_k *>(bb), hi = *reinterpret_cast<const f4u_k *>(bb + 4);
+            const float b8 = bb[8];
+            const bool z = j[d] < 0;
+            b0[d] = vf4{z ? 0.f : lo.x, z ? 0.f : lo.w, z ? 0.f : lo.y, z ? 0.f : hi.x};     // b00 b10 b01 b11
+            b1[d] = vf4{z ? 0.f : lo.z, z ? 0.f : hi.y, z ? 0.f : hi.z, z ? 0.f : hi.w};     // b02 b12 b20 b21
+            b2[d] = z ? 0.f : b8;
+        }
+    }
     __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)
     {
         const float *vb = sd.val + (int64_t)doff * 576;
@@ -337,6 +365,9 @@ template <int DMAX, bool SIGNED = false> struct OpCsrV3 {
 
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+template <class Op> struct is_direct { static constexpr bool value = false; };
+template <int DMAX> struct is_direct<OpBsr3<DMAX, true>> { static constexpr bool value = true; };
+
 // n floats global -> LDS without passing through registers (LDS-DMA, one dword per lane, 256 B per wave-instruction);
 // completion is counted in vmcnt like any load.
 template <int NT>
@@ -598,7 +629,11 @@ k_chain_sell(const int *__restrict__ col, const float *__restrict__ val, SellDev
         const int gs = __builtin_amdgcn_readlane(sw, 3), rows = __builtin_amdgcn_readlane(sw, 4);
         // the operator registers are dead here: refill them ...
         STAMP(li, 0);
-        op.load(sd, doff, poff, w, lane);
+        if constexpr (is_direct<Op>::value) {
+            const int rr = (rt & 0x3ff) == 0x3ff ? -1 : (rt & 0x3ff);
+            op.load_direct(sd, val, doff, poff, w, lane, rr >= 0 ? sd.rowptr[gs + rr] : 0);
+        } else
+            op.load(sd, doff, poff, w, lane);
         STAMP(li, 1);
         // ... and store the previous part's result underneath the stream
         if (prev_rows >= 0) {

@@ -111,10 +111,11 @@ def _closed_row_ranges(rowptr: torch.Tensor, col: torch.Tensor, n: int, target: 
     return torch.from_numpy(out.astype(np.int32)).to(dev), len(out) - 1, max_rows
 
 
-def _row_blocks_from_marks(delta: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, n: int, target: int):
+def _row_blocks_from_marks(delta: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, n: int, target: int, bad=None):
     """_closed_row_ranges for a pattern whose row-cover marks are already there (escat_ingest_coo_cover): one library
     call (three small kernels, one copy of the cuts to the host, the merge there) and the upload of the part
-    boundaries.  The result enters the parts cache, where Q of the same batch finds it."""
+    boundaries.  The result enters the parts cache, where Q of the same batch finds it.  bad: the ingest's flag word
+    (device), read in the same round trip -- returns None when it is set."""
     import ctypes
     from . import _lib
     lib = _lib.load()
@@ -122,11 +123,14 @@ def _row_blocks_from_marks(delta: torch.Tensor, rowptr: torch.Tensor, col: torch
     ws = torch.empty(lib.escat_row_blocks_workspace_bytes(n) // 4, dtype=torch.int32, device=dev)
     cap = n + 2                                          # (never touched beyond the boundaries written)
     out = np.empty(cap, dtype=np.int32)
-    mx = ctypes.c_int32(0)
+    mx, flag = ctypes.c_int32(0), ctypes.c_int32(0)
     with torch.cuda.device(dev):
         k = lib.escat_row_blocks(ctypes.c_void_p(delta.data_ptr()), n, target, ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4,
                                  out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(mx),
+                                 ctypes.c_void_p(bad.data_ptr() if bad is not None else 0), ctypes.byref(flag),
                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if bad is not None and flag.value:
+        return None
     if k < 0:
         _lib.check(int(k), "escat_row_blocks")
     if k < 2:
@@ -240,6 +244,8 @@ HALF_MAX_DMAX = 20
 # "auto" -- a BSR-3 operator whose blocks are p_ij G_i S_ij G_j^T to within FACTOR_TOL x max|Q| runs the vector chain in
 # the factored kernel (3 FMAs per entry instead of 9, two workgroups per CU); "0" -- never.
 FACTOR_MODE = os.environ.get("ESCAT_Q_FACTOR", "auto")
+# "direct" BSR-3 chains (no value pack, include/escat.h: escat_sell.ent_of_slot) for single-use operators; "0": never
+DIRECT_MODE = os.environ.get("ESCAT_Q_DIRECT", "auto")
 FACTOR_TOL = 1e-6
 
 # How much to invest in an operator at ingest.
@@ -253,6 +259,12 @@ FACTOR_TOL = 1e-6
 #     same tensor object comes back (ScatterOperator.promote): a batch seen once never pays for a plan it cannot use, a
 #     batch that is reused pays once, at its second use.
 INGEST_POLICY = os.environ.get("ESCAT_INGEST", "auto")
+
+
+def _fp16_probe(vals: torch.Tensor) -> torch.Tensor:
+    """a few thousand values: are they exact in fp16?  (0-d bool tensor on the device; the caller decides when to read it)"""
+    v = vals.reshape(-1)[:: max(1, vals.numel() // 4096)]
+    return (v.to(torch.float16).to(torch.float32) == v).all()
 
 
 def _policy_of(form) -> str:
@@ -310,6 +322,7 @@ class Sell:
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             self.half_val = self.half_aux = None
+            self.direct = False
             if shared is not None:
                 dims = shared._dims
                 self.lc, self.lane_meta, ws, self._ent = shared.lc, shared.lane_meta, shared._ws, shared._ent
@@ -325,6 +338,12 @@ class Sell:
                                                                  vp(shared._ent), vp(shared.lc), vp(self.val), vp(self.lc), st),
                                "escat_sell_pack_refill_signed")
                     self._ent = None             # (its lc carries sign bits: not a plan others may share)
+                elif V == 9 and self.half_val is None and _policy_of(form) == "single_use" and DIRECT_MODE != "0" \
+                        and self._ent is not None:
+                    # an operator seen once, on a plan that is already there (P's of the same batch): no value pack -- the
+                    # chain reads the blocks from the canonical array through the plan (escat_sell.ent_of_slot)
+                    self.val = None
+                    self.direct = True
                 elif self.half_val is None or HALF_MODE == "both":
                     self.val = torch.empty((dims.total_d + 1) * per, dtype=torch.float32, device=dev)
                     _lib.check(lib.escat_sell_pack_refill(vp(form.rowptr), vp(form.val), n, vp(form.part_ptr), form.n_parts, V,
@@ -403,8 +422,9 @@ class Sell:
         from . import _lib
         if HALF_MODE == "0" or self.layout != 1 or int(dims.dmax) > HALF_MAX_DMAX:
             return
-        v = form.val.reshape(-1)[:: max(1, form.val.numel() // 4096)]       # a cheap probe before the full pass: a few
-        if not bool((v.to(torch.float16).to(torch.float32) == v).all()):     # thousand values settle most operators
+        if form.fp16_probe is None:                  # a cheap probe before the full pass: a few thousand values settle
+            form.fp16_probe = bool(_fp16_probe(form.val))                    # most operators
+        if not form.fp16_probe:
             return
         dev = form.rowptr.device
         vp = lambda t_: ctypes.c_void_p(t_.data_ptr())
@@ -421,7 +441,7 @@ class Sell:
     def _capacity_for(V, cand) -> int:
         """the capacity escat_sell_pack_plan would choose for V values per entry on cand's row-length histogram"""
         if getattr(cand, "_hist_host", None) is None:
-            cand._hist_host = cand._hist.cpu().tolist()
+            cand._hist_host = list(cand._dims.row_len_hist)       # came back with the plan: no round trip here
             cand._n_rows = int(cand.pos_of_row.numel())
         caps = _SELL_DMAX[V]
         allowed = int(_SELL_TAIL_ROWS * cand._n_rows)
@@ -481,7 +501,7 @@ class SellGlobal:
 
 class _Csr:
     __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "_max_row_nnz", "_sell", "_sell_g",
-                 "_signed", "policy")
+                 "_signed", "policy", "fp16_probe")
 
     def __init__(self, rowptr, col, val, n, parts=None):
         self.rowptr, self.col, self.val, self.n = rowptr, col, val, n
@@ -494,6 +514,7 @@ class _Csr:
         self._sell_g = None
         self._signed = None
         self.policy = None              # None: the module's INGEST_POLICY; set by the owning ScatterOperator
+        self.fp16_probe = None          # _fp16_probe(val), when somebody has asked already
 
     @property
     def max_row_nnz(self) -> int:
@@ -555,6 +576,7 @@ class ScatterOperator:
         self._factored = None           # see factored(): FactoredVectorOperator, or False once recovery was refused
         self.factor_err = None          # relative reconstruction error of the recovery (diagnostic)
         self.policy = None              # None: the module's INGEST_POLICY ("auto" = full); as_operator sets "single_use"
+        self._fp16_probe = None         # values_look_fp16(), once
 
     def _stamp(self, form):
         if form is not None and self.policy is not None:
@@ -693,10 +715,13 @@ class ScatterOperator:
                     flags = torch.zeros(1, dtype=torch.int32, device=dev)
                     _lib.check(lib.escat_ingest_coo_like(vp(r), vp(c), nnz, n, vp(crp), vp(ccl), nnz // 9, vp(flags), st),
                                "escat_ingest_coo_like")
+                    v32 = val.to(torch.float32)
+                    probe = _fp16_probe(v32)             # queued behind the check: both answers in one round trip
                     f = int(flags.item())
                     if f == 0:
                         op = ScatterOperator(n, dev)
-                        op._bsr = _Csr(crp, ccl, val.to(torch.float32).reshape(-1, 3, 3).contiguous(), n // 3, hit[3])
+                        op._bsr = _Csr(crp, ccl, v32.reshape(-1, 3, 3).contiguous(), n // 3, hit[3])
+                        op._fp16_probe = op._bsr.fp16_probe = bool(probe)
                         op.bsr_fill = 1.0
                         op._reorder_if_large()
                         return op
@@ -717,7 +742,12 @@ class ScatterOperator:
                     delta = torch.empty(n + 1, dtype=torch.int32, device=dev)
                     _lib.check(lib.escat_ingest_coo_cover(vp(r), vp(c), nnz, n, vp(rowptr), vp(col32), vp(bad), vp(delta), st),
                                "escat_ingest_coo_cover")
-                if int(bad.item()):
+                marks_parts = None
+                if delta is not None:                    # the flag comes back with the cuts: one round trip
+                    marks_parts = _row_blocks_from_marks(delta, rowptr, col32, n, PART_TARGET_ROWS, bad=bad)
+                    if marks_parts is None:
+                        continue
+                elif int(bad.item()):
                     continue
                 op = ScatterOperator(n, dev)
                 op._graph_ptr = gp
@@ -727,7 +757,7 @@ class ScatterOperator:
                     op._bsr = _Csr(rowptr, col32, v32.reshape(-1, 3, 3).contiguous(), n // 3, parts)
                     op.bsr_fill = 1.0
                 else:
-                    parts = op._parts_for(1) if gp is not None else _row_blocks_from_marks(delta, rowptr, col32, n, PART_TARGET_ROWS)
+                    parts = op._parts_for(1) if gp is not None else marks_parts
                     op._csr = _Csr(rowptr, col32, v32.contiguous(), n, parts)
                     if n % 3 == 0:
                         op._maybe_bsr3_from_csr()
@@ -875,8 +905,11 @@ class ScatterOperator:
         b = self._bsr
         if b is None or b.nnz == 0:
             return False
-        v = b.val.reshape(-1)[:: max(1, b.val.numel() // 4096)]
-        return bool((v.to(torch.float16).to(torch.float32) == v).all())
+        if self._fp16_probe is None:
+            if b.fp16_probe is None:
+                b.fp16_probe = bool(_fp16_probe(b.val))
+            self._fp16_probe = b.fp16_probe
+        return self._fp16_probe
 
     def factored(self):
         """Q = D Pt D^T recovered from the blocks (include/escat.h: escat_recover_factored): a FactoredVectorOperator that

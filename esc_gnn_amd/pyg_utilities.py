@@ -114,7 +114,8 @@ def _chain_launch(op, plan_events, T, F, inp: torch.Tensor, C: int, backward: bo
         sell_struct = _lib.EscatSell(sell.val.data_ptr() if sell.val is not None else 0, sell.lc.data_ptr(), sell.lane_meta.data_ptr(),
                                      sell.dmax, sell.n_slices, sell.slices_per_part, sell.val_planes, 0, 0, 0, pl, pr, nl, orders,
                                      frames.data_ptr() if frames is not None else 0, sell.layout, sell.pos_of_row.data_ptr(),
-                                     sell.half_val.data_ptr() if half else 0, sell.half_aux.data_ptr() if half else 0)
+                                     sell.half_val.data_ptr() if half else 0, sell.half_aux.data_ptr() if half else 0,
+                                     sell._ent.data_ptr() if getattr(sell, "direct", False) else 0)
         sell_ref = ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p)
     elif not fused and use_bsr and T > 0 and path == "multi_packed":
         # experimental (opt-in): whole-operator SELL pack with global columns for the multi-launch path.  Measured on

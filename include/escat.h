@@ -148,6 +148,12 @@ typedef struct {
      * NULL when half_val is given (lc is not read either, but must be non-NULL). */
     const void     *half_val;
     const uint32_t *half_aux;
+    /* Round 3, BSR-3 only, optional: val == NULL, half_val == NULL and ent_of_slot != NULL = "direct" -- no value pack at
+     * all: the chain reads every row's blocks from the canonical blk array it is given anyway (entry rowptr[row] +
+     * ent_of_slot[(doff_s + d) * 64 + lane] sits in slot d; -1 = a padded slot), following the plan of a pack with the
+     * same pattern (P of the batch: lc / lane_meta / pos_of_row are that pack's).  For an operator that is used once:
+     * packing its 36 B per block costs more than the strided reads of one chain. */
+    const int8_t *ent_of_slot;
 } escat_sell;
 
 /* ---- the pack itself, built on the GPU (replaces round 1's torch index ops; esc_gnn_amd/operators.py::Sell calls
@@ -168,6 +174,8 @@ typedef struct {
     int32_t dmax, n_slices, slices_per_part, layout;
     int64_t total_d, total_p;           /* slots / LDS-row pairs over all slices */
     int64_t val_floats, lc_words;       /* elements of val / lc to allocate (padding slot / pair included) */
+    int32_t row_len_hist[34];           /* rows by length (33 = longer): what dmax was chosen from, for callers that decide
+                                         * whether a pack of another values_per_entry can share this plan (round 3) */
 } escat_sell_dims;
 size_t escat_sell_pack_workspace_bytes(int64_t n, int n_parts);
 int escat_sell_pack_plan(const int32_t *rowptr, int64_t n, const int32_t *part_ptr, int n_parts, int max_part_rows,
@@ -238,7 +246,8 @@ int64_t escat_merge_row_ranges(const int64_t *bounds, int64_t nb, int64_t target
  * escat_row_blocks: from those marks to the parts, in one call -- prefix sum, cuts and their compaction as three small
  *   kernels, the cuts copied to the host, escat_merge_row_ranges there.  Synchronises the stream.  delta is overwritten;
  *   workspace (device) of escat_row_blocks_workspace_bytes(n); out_host: room for out_cap boundaries (HOST).  Returns
- *   the number of boundaries or a negative error code;
+ *   the number of boundaries or a negative error code.  flag_dev / flag_host (optional): a device word -- the *bad of
+ *   the ingest that made the marks -- comes to the host in the same copy; when it is non-zero the call returns 0;
  * escat_ingest_coo_like: Q in block-emission order whose blocks sit exactly on a pattern already ingested (P of the same
  *   batch: ref_rowptr (n/3 + 1), ref_col (ref_nnz) = its canonical CSR).  Writes nothing but *flags (device, caller
  *   zeroes): 0 = same pattern, the caller reuses P's rowptr / col / parts / pack plan; bit 0 = not in block-emission
@@ -247,7 +256,8 @@ int escat_ingest_coo_cover(const int64_t *rows, const int64_t *cols, int64_t nnz
                            int32_t *rowptr, int32_t *col32, int32_t *bad, int32_t *delta, void *stream);
 size_t escat_row_blocks_workspace_bytes(int64_t n);
 int64_t escat_row_blocks(int32_t *delta, int64_t n, int64_t target, void *workspace, size_t workspace_bytes,
-                         int32_t *out_host, int64_t out_cap, int32_t *max_rows, void *stream);
+                         int32_t *out_host, int64_t out_cap, int32_t *max_rows, const int32_t *flag_dev, int32_t *flag_host,
+                         void *stream);
 int escat_ingest_coo_like(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n,
                           const int32_t *ref_rowptr, const int32_t *ref_col, int64_t ref_nnz, int32_t *flags, void *stream);
 

@@ -349,6 +349,60 @@ def test_like_ingest_recognises_the_pattern_of_the_batch():
     assert cq.sell().lc.data_ptr() == cp.sell().lc.data_ptr() or cq.sell().dmax != cp.sell().dmax      # one plan for both
 
 
+def test_direct_chain_without_a_value_pack_equals_the_packed_chain(oracle_lib, monkeypatch):
+    """round 3 (escat_sell.ent_of_slot): a Q that is seen once and arrives after its batch's P runs the BSR-3 register
+    kernel straight from the canonical blocks, on P's plan -- bit for bit what the same plan gives with a value pack
+    (ESCAT_Q_DIRECT=0), forward, backward and with the orders epilogue fused, and within 1e-5 of the C oracle.  Ragged
+    graphs, 512- and 256-thread parts, rows longer than the capacity (tails)."""
+    from esc_gnn_amd import get_Batch_Wjxs, scatter, synthetic, plan_chain, operators, as_operator
+    from tests.test_gpu_parity import _concat_batches
+    dev = _dev()
+    cases = [_concat_batches([synthetic.ellipsoid_batch(5, 300, 8, seed=1), synthetic.ellipsoid_batch(3, 500, 10, seed=2),
+                              synthetic.ellipsoid_batch(20, 30, 4, seed=3)]),
+             synthetic.ellipsoid_batch(12, 200, 6, seed=4),
+             synthetic.ellipsoid_batch(2, 400, 26, seed=5)]
+    kw = dict(scales_type="dyadic", J=3)
+    plan = plan_chain(**kw)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    n_shared = 0
+    for b in cases:
+        rows, cols, qr, qc = _coo_of(b)
+        N = b["N"]
+        Pi, Qi = torch.from_numpy(np.stack([rows, cols])).to(dev), torch.from_numpy(np.stack([qr, qc])).to(dev)
+        Pv, Qv = torch.from_numpy(b["pval"]).to(dev), torch.from_numpy(b["blk"].reshape(-1)).to(dev)
+        xv = torch.from_numpy(b["pos"]).reshape(-1, 1).to(dev)
+        xs = torch.from_numpy(b["pos"]).to(dev)
+        outs = {}
+        for mode in ("auto", "0"):
+            monkeypatch.setattr(operators, "DIRECT_MODE", mode)
+            operators._PLAN_CACHE.clear(); operators._PARTS_CACHE.clear()
+            P = torch.sparse_coo_tensor(Pi, Pv, (N, N), check_invariants=False)
+            Q = torch.sparse_coo_tensor(Qi, Qv, (3 * N, 3 * N), check_invariants=False)
+            get_Batch_Wjxs(xs, P, **kw)
+            x = xv.clone().requires_grad_(True)
+            W = get_Batch_Wjxs(x, Q, **kw)
+            opq = Q._escat_operator
+            # (P's and Q's packs share a plan when the capacity rule picks the same dmax for both: not for every histogram)
+            shared = opq.bsr3().sell().lc.data_ptr() == P._escat_operator.csr().sell().lc.data_ptr()
+            n_shared += int(shared)
+            assert opq.policy == "single_use" and opq.bsr3().sell().direct == (mode == "auto" and shared)
+            assert (opq.bsr3().sell().val is None) == (mode == "auto" and shared)
+            G = torch.randn(W.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+            (W * G).sum().backward()
+            assert opq.bsr3_t().sell().direct == (mode == "auto")      # the transpose always finds a plan: Q's own, or P's
+            with torch.no_grad():
+                Q2 = torch.sparse_coo_tensor(Qi, Qv, (3 * N, 3 * N), check_invariants=False)
+                S = scatter(track="vector", x0=xs, P_or_Q=Q2, kwargs=dict(diffusion_kwargs=kw))
+            outs[mode] = (W.detach(), x.grad.clone(), S, G)
+        assert torch.equal(outs["auto"][0], outs["0"][0]) and torch.equal(outs["auto"][1], outs["0"][1])
+        assert torch.equal(outs["auto"][2], outs["0"][2])
+        W, gx, S, G = outs["auto"]
+        _close(W, co.c_chain_bsr3(b["rowptr"], b["col"], b["blk"], xv.cpu().numpy().reshape(-1), ev, plan.T, plan.F))
+        _close(gx, co.c_chain_bsr3_bwd(b["rowptr"], b["col"], b["blk"], G.cpu().numpy(), ev, plan.T), rtol=1e-5)
+        assert torch.equal(S[..., 0].reshape(-1, 1), xv) and torch.equal(S[..., 1:1 + plan.F].reshape(W.shape), W)
+    assert n_shared >= 4, n_shared                       # the direct kernel really ran (both modes of >= 2 cases)
+
+
 @pytest.mark.parametrize("graphs,n,k", [(3, 1500, 6), (2, 1100, 40), (1, 37, 5)])
 def test_bsr3_step_staged_vs_oracle(monkeypatch, graphs, n, k):
     """Multi-launch vector chain through the LDS-staged step kernel (k_bsr3_step_staged, the default) and through the
