@@ -549,7 +549,7 @@ extern "C" int escat_sell_pack_plan(const int32_t *rowptr, int64_t n, const int3
     hipStream_t st = S(stream);
     hipError_t e = hipMemsetAsync(ws.hist, 0, 64 * sizeof(int), st);
     if (e != hipSuccess) return fail(ESCAT_ELAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-    int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    int64_t blocks = (n + 255) / 256; if (blocks > 512) blocks = 512;     // (every block ends with 34 atomics on the same words)
     hipLaunchKernelGGL(k_pack_hist, dim3((unsigned)blocks), dim3(256), 0, st, rowptr, n, ws.hist);
     hipLaunchKernelGGL(k_pack_pick_dmax, dim3(1), dim3(64), 0, st, ws.hist, n, values_per_entry);
     hipLaunchKernelGGL(k_pack_order, dim3(n_parts), dim3(PACK_MAX_ROWS), 0, st, rowptr, part_ptr, ws.hist + 40, nsl, ws.perm, ws.pos, ws.w);
@@ -940,7 +940,7 @@ extern "C" int escat_ingest_coo_like(const int64_t *rows, const int64_t *cols, i
     if (n <= 0 || nnz <= 0 || n % 3 || nnz % 9) return fail(ESCAT_EINVAL, "a BSR-3 ingest needs n %% 3 == 0 and nnz %% 9 == 0 (both > 0)");
     if (n >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return fail(ESCAT_ERANGE, "n or nnz >= 2^31 (int32 indices)");
     if (ref_nnz != nnz / 9) return fail(ESCAT_EINVAL, "the reference pattern has %lld entries, the operator %lld blocks", (long long)ref_nnz, (long long)(nnz / 9));
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int64_t nnzb = nnz / 9, waves = (nnzb + 7 * U - 1) / (7 * U);
     hipLaunchKernelGGL(k_coo_blocks_like<U>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S(stream),
                        (const long long *)rows, (const long long *)cols, nnzb, n / 3, ref_rowptr, ref_col, flags);
