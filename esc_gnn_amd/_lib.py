@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libescat.so")
+LIB_PATH = os.environ.get("ESCAT_LIB", os.path.join(_HERE, "libescat.so"))      # (ESCAT_LIB: tuning builds, tools/ only)
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_f32p = ctypes.POINTER(ctypes.c_float)

@@ -251,8 +251,12 @@ k_bsr3_step(const int *__restrict__ rowptr, const int *__restrict__ col, const f
 // three block rows out of LDS (odd strides: conflict-free).  tools/lds/step_bench.hip: 0.432 -> 0.316 ms per step on
 // a cfg3-shaped operator (5.0 TB/s), the same kernel without any x gather 0.27 ms.
 // A trip whose rows hold more than STG_CAP blocks is computed straight from global memory (same lanes, same order).
+#ifndef STG_RPB
 #define STG_RPB 32
-#define STG_CAP 768
+#endif
+#ifndef STG_CAP
+#define STG_CAP (STG_RPB * 24)
+#endif
 #define STG_NQ ((STG_CAP * 9 + 3) / 4 + 1)
 #define STG_LDS_BYTES ((STG_NQ * 4 + STG_CAP * 3 + STG_RPB + 4) * 4)
 typedef float escat_vf4 __attribute__((ext_vector_type(4)));
@@ -269,17 +273,40 @@ k_bsr3_step_staged(const int *__restrict__ rowptr, const int *__restrict__ col, 
     int *rpL = reinterpret_cast<int *>(xL + STG_CAP * 3);
     const int trips = (nb + STG_RPB - 1) / STG_RPB;
     const int64_t nfl = nnzb * 9;
-    for (int trip = blockIdx.x; trip < trips; trip += gridDim.x) {
+    // The columns of a trip are loaded one trip AHEAD (three registers): the chain rowptr -> col -> x of a trip is then one
+    // hop shorter on its critical path -- the next trip's row bounds and columns travel under this trip's value stream
+    // and compute (round 3; the fully pipelined variant of round 2, values included, lost occupancy and was slower).
+    int trip = blockIdx.x;
+    int e0 = 0, e1 = 0;
+    int c[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) c[j] = 0;
+    if (trip < trips) {
         const int r0 = trip * STG_RPB, r1 = r0 + STG_RPB < nb ? r0 + STG_RPB : nb;
-        const int e0 = rowptr[r0], e1 = rowptr[r1], ne = e1 - e0;
+        e0 = rowptr[r0]; e1 = rowptr[r1];
+        if (e1 - e0 <= STG_CAP) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) { const int i = threadIdx.x + 256 * j; c[j] = i < e1 - e0 ? col[e0 + i] : 0; }
+        }
+    }
+    for (; trip < trips; trip += gridDim.x) {
+        const int r0 = trip * STG_RPB, r1 = r0 + STG_RPB < nb ? r0 + STG_RPB : nb;
+        const int ne = e1 - e0;
         const bool staged = ne <= STG_CAP;
         const int64_t f0 = (int64_t)e0 * 9, a0 = f0 & ~(int64_t)3;
+        // the next trip's bounds first: they are the oldest loads in flight when its columns are asked for below
+        const int tripN = trip + gridDim.x;
+        int e0N = 0, e1N = 0;
+        if (tripN < trips) {
+            const int r0N = tripN * STG_RPB, r1N = r0N + STG_RPB < nb ? r0N + STG_RPB : nb;
+            e0N = rowptr[r0N]; e1N = rowptr[r1N];
+        }
+        int cN[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) cN[j] = 0;
         if (threadIdx.x <= r1 - r0) rpL[threadIdx.x] = rowptr[r0 + threadIdx.x] - e0;
         if (staged) {
             const int nq = (int)(((int64_t)e1 * 9 - a0 + 3) >> 2);
-            int c[EPT];
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) { const int i = threadIdx.x + 256 * j; c[j] = i < ne ? col[e0 + i] : 0; }
             float4 v[QPT];
 #pragma unroll
             for (int j = 0; j < QPT; ++j) {
@@ -299,6 +326,10 @@ k_bsr3_step_staged(const int *__restrict__ rowptr, const int *__restrict__ col, 
             for (int j = 0; j < EPT; ++j) {
                 const float *xp = xin + (int64_t)c[j] * 3;
                 xr[j][0] = xp[0]; xr[j][1] = xp[1]; xr[j][2] = xp[2];
+            }
+            if (tripN < trips && e1N - e0N <= STG_CAP) {
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) { const int i = threadIdx.x + 256 * j; cN[j] = i < e1N - e0N ? col[e0N + i] : 0; }
             }
 #pragma unroll
             for (int j = 0; j < QPT; ++j) { const int q = threadIdx.x + 256 * j; if (q < nq) *reinterpret_cast<float4 *>(vL + 4 * q) = v[j]; }
@@ -347,6 +378,13 @@ k_bsr3_step_staged(const int *__restrict__ rowptr, const int *__restrict__ col, 
                 for (int q = 0; q < ev.n; ++q) emit_one(o, y, ev.e[q].slot, ev.e[q].sign);
             }
         }
+        if (!staged && tripN < trips && e1N - e0N <= STG_CAP) {       // (the unstaged trip did not reach the prefetch above)
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) { const int i = threadIdx.x + 256 * j; cN[j] = i < e1N - e0N ? col[e0N + i] : 0; }
+        }
+        e0 = e0N; e1 = e1N;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) c[j] = cN[j];
         __syncthreads();
     }
 }

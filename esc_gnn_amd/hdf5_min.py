@@ -10,14 +10,18 @@ scripts/python/parallel_process_dataset.py:193-230; reader: models/escgnn_data_c
 
 Neither h5py nor libhdf5 exists in the build or GPU images, so this module writes the file format directly
 (HDF5 File Format Specification v3): superblock v2, version-2 object headers (Jenkins lookup3 checksums),
-new-style groups with compact link storage (Link Info + Link messages), datasets with contiguous layout
-(uncompressed -- the reference's reader does not require gzip, escgnn_data_classes.py:136-141).
+new-style groups with compact link storage (Link Info + Link messages), datasets with contiguous layout, or --
+`compression='gzip'`, what the reference's writers ask h5py for on indices / values
+(generate_ellipsoid_dataset.py:1192-1200, parallel_process_dataset.py:209-227) -- chunked layout with ONE chunk per
+dataset (layout message v3 class 2, a one-leaf version-1 chunk B-tree) behind a deflate filter (filter pipeline
+message v2, filter id 1, level 4 = h5py's default), stdlib zlib.
 
 PARITY UNPINNED: with no HDF5 library available the files are validated only against the spec as restated in
 `read()` below and against the lookup3 test vectors; a cross-check with h5py is the first thing to do where it exists.
 """
 import os
 import struct
+import zlib
 import numpy as np
 
 UNDEF = 0xFFFFFFFFFFFFFFFF
@@ -119,6 +123,27 @@ def _dataset_header(arr: np.ndarray, data_addr: int) -> bytes:
     return _ohdr(msgs)
 
 
+def _chunk_btree_leaf(shape, chunk_addr: int, stored: int) -> bytes:
+    """version-1 B-tree node (type 1: raw data chunks), one leaf with one chunk at offset 0: key 0 = (stored size, filter
+    mask 0, offsets 0.. + the element-size dimension), the chunk's address, key 1 = the first offsets beyond it."""
+    nd = len(shape)
+    body = b"TREE" + struct.pack("<BBH", 1, 0, 1) + struct.pack("<QQ", UNDEF, UNDEF)
+    body += struct.pack("<II", stored, 0) + struct.pack("<Q", 0) * (nd + 1) + struct.pack("<Q", chunk_addr)
+    body += struct.pack("<II", 0, 0) + b"".join(struct.pack("<Q", int(d)) for d in shape) + struct.pack("<Q", 0)
+    return body
+
+
+def _dataset_header_gzip(arr: np.ndarray, btree_addr: int, level: int) -> bytes:
+    msgs = _msg(0x01, _dataspace(arr.shape))
+    msgs += _msg(0x03, _datatype(arr.dtype))
+    msgs += _msg(0x05, struct.pack("<BB", 3, 0x09))                  # fill value v3: allocate incrementally (chunked), write if set
+    lay = struct.pack("<BBB", 3, 2, arr.ndim + 1) + struct.pack("<Q", btree_addr)
+    lay += b"".join(struct.pack("<I", int(d)) for d in arr.shape) + struct.pack("<I", arr.dtype.itemsize)
+    msgs += _msg(0x08, lay)                                          # chunked layout: the chunk is the whole dataset
+    msgs += _msg(0x0B, struct.pack("<BB", 2, 1) + struct.pack("<HHH", 1, 0x0001, 1) + struct.pack("<I", level))   # deflate, optional
+    return _ohdr(msgs)
+
+
 def _group_header(links) -> bytes:
     """links: list of (name, address). Link Info (compact storage) + one Link message per child."""
     msgs = _msg(0x02, struct.pack("<BBQQ", 0, 0, UNDEF, UNDEF))      # link info: no creation order, no heap, no index
@@ -168,7 +193,11 @@ class H5Writer:
         self.pos += len(b)
         return addr
 
-    def write(self, path: str, arr) -> None:
+    def write(self, path: str, arr, compression=None, compression_opts: int = 4, _deflated=None) -> None:
+        """compression: None (contiguous) or 'gzip' (h5py's create_dataset(..., compression='gzip'): one deflated chunk;
+        scalars and empty arrays stay contiguous, as a chunked dataset needs rank >= 1 and data)."""
+        if compression not in (None, "gzip"):
+            raise ValueError(f"hdf5_min: compression {compression!r} (None or 'gzip')")
         arr = np.ascontiguousarray(arr)
         if arr.dtype.byteorder == ">":
             arr = arr.astype(arr.dtype.newbyteorder("<"))
@@ -180,8 +209,30 @@ class H5Writer:
                 raise ValueError(f"{p} is a dataset, not a group")
         if parts[-1] in node:
             raise ValueError(f"{path} already exists")
+        if compression == "gzip" and arr.ndim >= 1 and arr.nbytes and all(d < (1 << 32) for d in arr.shape):
+            raw = _deflated if _deflated is not None else zlib.compress(arr.tobytes(), int(compression_opts))
+            chunk_addr = self._append(raw)
+            btree = self._append(_chunk_btree_leaf(arr.shape, chunk_addr, len(raw)))
+            node[parts[-1]] = self._append(_dataset_header_gzip(arr, btree, int(compression_opts)))
+            return
         data_addr = self._append(arr.tobytes()) if arr.nbytes else UNDEF
         node[parts[-1]] = self._append(_dataset_header(arr, data_addr))
+
+    def write_many(self, items, compression=None, compression_opts: int = 4, threads: int = 0) -> None:
+        """items: list of (path, array) or (path, array, deflate?).  With compression='gzip' the chunks are deflated by a pool of threads (zlib
+        releases the GIL) and appended in order: a dataset file is ~1e5 small datasets, one core deflates ~50 MB/s."""
+        items = [(it[0], np.ascontiguousarray(it[1]), (it[2] if len(it) > 2 else True)) for it in items]   # (path, array[, deflate this one])
+        if compression != "gzip" or len(items) < 2:
+            for p, a, z in items:
+                self.write(p, a, compression if z else None, compression_opts)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        threads = threads or min(16, os.cpu_count() or 1)
+        lvl = int(compression_opts)
+        with ThreadPoolExecutor(threads) as pool:
+            raws = list(pool.map(lambda it: zlib.compress(it[1].tobytes(), lvl) if it[2] and it[1].ndim >= 1 and it[1].nbytes else None, items))
+        for (p, a, z), raw in zip(items, raws):
+            self.write(p, a, compression if z else None, compression_opts, _deflated=raw)
 
     def _flush_group(self, node) -> int:
         links = []
@@ -271,10 +322,30 @@ class H5Reader:
         rank = sp[1]
         shape = tuple(struct.unpack("<Q", sp[4 + 8 * i:12 + 8 * i])[0] for i in range(rank))
         dtype = _DT[(ty[0] & 0x0F, struct.unpack("<I", ty[4:8])[0])]
+        if lay[0] == 3 and lay[1] == 2:                              # chunked (+ filters): the classic reader's chunk walk
+            from .hdf5_classic import ClassicH5Reader, _ClassicDataset
+            nd = lay[2]
+            a = struct.unpack("<Q", lay[3:11])[0]
+            dims = struct.unpack("<" + "I" * nd, lay[11:11 + 4 * nd])
+            filters = ClassicH5Reader._parse_filters(d.get(0x0B))
+            return _ClassicDataset(self, shape, np.dtype(dtype), "chunked", None if a == UNDEF else a, dims[:-1], filters)
         if lay[0] != 3 or lay[1] != 1:
-            raise ValueError("only contiguous layout is supported")
+            raise ValueError("only contiguous and chunked layouts are supported")
         daddr, dsize = struct.unpack("<QQ", lay[2:18])
         return _Dataset(self, shape, np.dtype(dtype), daddr, dsize)
+
+    # what hdf5_classic's chunk walk asks of its file object
+    O, L, base = 8, 8, 0
+
+    def _bytes(self, p, n):
+        return bytes(self.buf[p:p + n])
+
+    def _int(self, p, n):
+        return int.from_bytes(self._bytes(p, n), "little")
+
+    def _chunks(self, btree_addr, nd):
+        from .hdf5_classic import ClassicH5Reader
+        return ClassicH5Reader._chunks(self, btree_addr, nd)
 
     def __getitem__(self, key):
         return self.node(self.root)[key]
@@ -339,21 +410,23 @@ def open_h5(path: str):
 
 
 # ------------------------------------------------------------------ the reference's operator file
-def write_operator_file(path, graphs, op_keys=("P", "Q")):
+def write_operator_file(path, graphs, op_keys=("P", "Q"), compression="gzip"):
     """graphs: iterable of (idx, dict) with dict[op] = {'indices','values','size'} (torch tensors or arrays),
-    i.e. what process_pyg_data(..., return_data_object=False) returns; optional 'edge_index'/'edge_weight'."""
+    i.e. what process_pyg_data(..., return_data_object=False) returns; optional 'edge_index'/'edge_weight'.
+    compression: 'gzip' (default, as the reference: indices / values deflated, size plain --
+    generate_ellipsoid_dataset.py:1192-1205) or None (contiguous: 2-3x the bytes, a faster write)."""
     def _np(x):
         return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
     with H5Writer(path) as f:
         for idx, d in graphs:
             for op in op_keys:
-                f.write(f"{op}/{idx}/indices", _np(d[op]["indices"]).astype(np.int64))
-                f.write(f"{op}/{idx}/values", _np(d[op]["values"]))
+                f.write(f"{op}/{idx}/indices", _np(d[op]["indices"]).astype(np.int64), compression=compression)
+                f.write(f"{op}/{idx}/values", _np(d[op]["values"]), compression=compression)
                 f.write(f"{op}/{idx}/size", np.array(tuple(d[op]["size"]), dtype=np.int64))
-            if "edge_index" in d:
-                f.write(f"edge_index/{idx}/values", _np(d["edge_index"]).astype(np.int64))
+            if "edge_index" in d:                        # parallel_process_dataset.py:216-219: gzip too
+                f.write(f"edge_index/{idx}/values", _np(d["edge_index"]).astype(np.int64), compression=compression)
             if "edge_weight" in d:
-                f.write(f"edge_weight/{idx}/values", _np(d["edge_weight"]))
+                f.write(f"edge_weight/{idx}/values", _np(d["edge_weight"]), compression=compression)
 
 
 def merge_h5_files(path, shard_paths, remove_shards=True):
@@ -377,7 +450,8 @@ def merge_h5_files(path, shard_paths, remove_shards=True):
                     if name in seen:
                         continue
                     seen.add(name)
-                    out.write(name, np.asarray(ds[...]))
+                    gz = any(fl[0] == 1 for fl in (getattr(ds, "filters", None) or []))     # a deflated dataset stays deflated
+                    out.write(name, np.asarray(ds[...]), compression="gzip" if gz else None)
             finally:
                 f.close()
     if remove_shards:

@@ -312,8 +312,11 @@ def process_pyg_data(
 def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k: int,
                        local_pca_kernel_fn_kwargs: Dict[str, Any], hdf5_tensor_dtype: str = "float16",
                        chunk_graphs: int = 16384, store_frames: bool = False, index_offset: int = 0,
-                       **build_kwargs) -> Dict[str, Any]:
+                       compression: Optional[str] = "gzip", **build_kwargs) -> Dict[str, Any]:
     """
+    compression: 'gzip' (default) writes indices / values as the reference does (create_dataset(..., compression='gzip'),
+    generate_ellipsoid_dataset.py:1192-1200; chunks deflated by a thread pool), None writes them contiguous (2-3x the
+    bytes, several times the write rate: for scratch files that only esc_gnn_amd.store reads back).
     The P/Q -> HDF5 loop of scripts/python/generate_ellipsoid_dataset.py:1165-1213 for a whole dataset: graphs are
     built on the GPU in chunks (build_PQ_batch), the per-graph COO arrays of the reference layout are formed on the
     GPU for the whole chunk, copied to the host once and written by esc_gnn_amd.hdf5_min (atomic rename at the end).
@@ -350,18 +353,22 @@ def write_dataset_hdf5(path: str, pos: torch.Tensor, graph_ptr: torch.Tensor, k:
             Q_c = ((3 * lcol)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1).cpu().numpy()
             gpn = gp.numpy()
             fr = b["frames"].cpu().numpy() if store_frames else None
+            items = []
             for g in range(g1 - g0):
                 e0, e1 = int(eoff[g]), int(eoff[g + 1])
                 ng = int(gpn[g + 1] - gpn[g])
                 idx = index_offset + g0 + g
-                f.write(f"P/{idx}/indices", P_idx[:, e0:e1])
-                f.write(f"P/{idx}/values", P_val[e0:e1])
-                f.write(f"P/{idx}/size", np.array([ng, ng], dtype=np.int64))
-                f.write(f"Q/{idx}/indices", np.stack([Q_r[9 * e0:9 * e1], Q_c[9 * e0:9 * e1]]))
-                f.write(f"Q/{idx}/values", Q_val[9 * e0:9 * e1])
-                f.write(f"Q/{idx}/size", np.array([3 * ng, 3 * ng], dtype=np.int64))
+                items.append((f"P/{idx}/indices", P_idx[:, e0:e1]))
+                items.append((f"P/{idx}/values", P_val[e0:e1]))
+                items.append((f"P/{idx}/size", np.array([ng, ng], dtype=np.int64), False))       # plain, as the reference's
+                items.append((f"Q/{idx}/indices", np.stack([Q_r[9 * e0:9 * e1], Q_c[9 * e0:9 * e1]])))
+                items.append((f"Q/{idx}/values", Q_val[9 * e0:9 * e1]))
+                items.append((f"Q/{idx}/size", np.array([3 * ng, 3 * ng], dtype=np.int64), False))
                 if store_frames:
-                    f.write(f"frames/{idx}/values", fr[int(gpn[g]):int(gpn[g + 1])])
+                    items.append((f"frames/{idx}/values", fr[int(gpn[g]):int(gpn[g + 1])]))
+                if len(items) >= 2048 or g == g1 - g0 - 1:
+                    f.write_many(items, compression=compression)
+                    items = []
     return {"graphs": B, "nnz": total_nnz, "path": path}
 
 

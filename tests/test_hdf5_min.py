@@ -65,6 +65,58 @@ def test_operator_file_round_trip(tmp_path, bg):
     f.close()
 
 
+def test_gzip_datasets_round_trip_and_shrink(tmp_path, bg):
+    """round 3: compression='gzip' (what the reference asks h5py for on indices / values,
+    generate_ellipsoid_dataset.py:1192-1200): one deflated chunk per dataset behind a version-1 chunk B-tree; read back
+    through the chunk walk of the classic reader; sizes stay plain; the file is several times smaller than the
+    contiguous one at the reference's dtypes (int64 indices, fp16 values).  PARITY UNPINNED as the rest of the writer:
+    no HDF5 library here to read it."""
+    graphs = []
+    for ci in range(4):
+        p = f"g{ci}_"
+        graphs.append((ci, {"P": {"indices": bg[p + "P_indices"], "values": bg[p + "P_values_f16"], "size": bg[p + "P_size"]},
+                            "Q": {"indices": bg[p + "Q_indices"], "values": bg[p + "Q_values_f16"], "size": bg[p + "Q_size"]},
+                            "edge_index": bg[p + "edge_index"]}))
+    pz, pc = str(tmp_path / "z.h5"), str(tmp_path / "c.h5")
+    h5.write_operator_file(pz, graphs)                       # default: gzip
+    h5.write_operator_file(pc, graphs, compression=None)
+    assert os.path.getsize(pz) < 0.5 * os.path.getsize(pc)
+    fz, fc = h5.open_h5(pz), h5.open_h5(pc)
+    for ci in range(4):
+        for op in ("P", "Q"):
+            for name in ("indices", "values", "size"):
+                a, b = fz[op][str(ci)][name], fc[op][str(ci)][name]
+                assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a[...], b[...]), (ci, op, name)
+        assert np.array_equal(fz[f"edge_index/{ci}/values"][...], bg[f"g{ci}_edge_index"])
+    # the layout itself: chunked (class 2) with the whole array as the chunk, deflate in the pipeline, size contiguous
+    d = fz["Q"]["0"]["indices"]
+    assert d.kind == "chunked" and tuple(d.chunk) == tuple(bg["g0_Q_indices"].shape) and d.filters == [(1, 1, (4,))]
+    assert not hasattr(fz["Q"]["0"]["size"], "kind")
+    # slices, empty and scalar datasets, a pool of writers
+    p2 = str(tmp_path / "m.h5")
+    rng = np.random.default_rng(0)
+    arrs = {f"a/{i}": rng.integers(0, 50, (2, 100 + i)).astype(np.int64) for i in range(40)}
+    with h5.H5Writer(p2) as w:
+        w.write_many([(k, v) for k, v in arrs.items()] + [("a/plain", np.arange(5, dtype=np.int64), False)], compression="gzip")
+        w.write("e/empty", np.zeros((2, 0), dtype=np.int64), compression="gzip")
+        w.write("e/scalar", np.float32(3.5), compression="gzip")
+    f2 = h5.open_h5(p2)
+    for k, v in arrs.items():
+        assert np.array_equal(f2[k][...], v) and np.array_equal(f2[k][1, 5:9], v[1, 5:9])
+    assert f2["a/plain"][...].tolist() == [0, 1, 2, 3, 4] and f2["e/empty"][...].shape == (2, 0) and float(np.asarray(f2["e/scalar"][...]).reshape(-1)[0]) == 3.5
+    with pytest.raises(ValueError):
+        with h5.H5Writer(str(tmp_path / "bad.h5")) as w:
+            w.write("x", np.zeros(3), compression="lzf")
+    # a flipped byte inside a deflated chunk does not go unnoticed (zlib's adler32)
+    raw = bytearray(open(p2, "rb").read())
+    dd = f2["a/0"]
+    offs, addr, csize, fmask = f2._chunks(dd.where, 2)[0]
+    raw[addr + csize // 2] ^= 0x55
+    open(p2, "wb").write(bytes(raw))
+    with pytest.raises(Exception):
+        h5.open_h5(p2)["a/0"][...]
+
+
 def test_corruption_is_detected(tmp_path):
     path = str(tmp_path / "x.h5")
     with h5.H5Writer(path) as w:
