@@ -14,7 +14,8 @@ scripts/python/generate_ellipsoid_dataset.py:1165-1183).
 Kernel steps and their reference lines are listed in include/escat.h.  Graph construction: 'k-nn' (the default, with the
 Gaussian RBF x cosine-cutoff edge weights of build_weighted_radius_adjacency, :173-232), 'radius' (all neighbours inside
 r_cutoff among the max_num_neighbors <= 32 nearest -- torch-cluster's choice of WHICH neighbours survive its cap is
-unpinned; identical whenever the cap is not reached), 'reweight_existing_edges', or None (a given edge_index).
+unpinned; identical whenever the cap is not reached), 'reweight_existing_edges' (with the reference's pairing of
+coalesced weights and un-coalesced edge list, see process_pyg_data below), or None (a given edge_index).
 rank_deficiency_strategy='Tikhonov' is supported (:262-279).  Not reproduced: Bessel edge features and Dirac selection
 (QM9 path, out of scope) and custom kernel callables: these raise NotImplementedError.
 """
@@ -271,6 +272,17 @@ def process_pyg_data(
         gauss = torch.exp(-((dists / gck['gaussian_eps']) ** 2))
         cosine_cut = 0.5 * (torch.cos(math.pi * dists / gck['r_cutoff']) + 1.0)
         edge_weight = gauss * cosine_cut
+        if graph_construction == 'reweight_existing_edges':
+            # The reference keeps the weights of the COALESCED adjacency (A_sparse._values(), :758: row-major order,
+            # duplicates summed) and get_P pairs them with the edge list in its ORIGINAL order (:563-579): on an edge
+            # list that is not row-major sorted the weights land on other edges.  Reproduced as it is (golden
+            # tests/golden/round3b_goldens.npz); duplicate edges make the two lengths differ, where the reference fails.
+            av = torch.sparse_coo_tensor(edge_index, edge_weight, (n, n)).coalesce().values()
+            if av.numel() != edge_weight.numel():
+                raise ValueError("escat: 'reweight_existing_edges' with duplicate edges: the coalesced weights "
+                                 f"({av.numel()}) no longer match the edge list ({edge_weight.numel()}); the reference "
+                                 "fails here too (to_torch_coo_tensor, process_pyg_data.py:575)")
+            edge_weight = av
         try:
             data.edge_index, data.edge_weight = edge_index, edge_weight
         except Exception:
@@ -282,7 +294,7 @@ def process_pyg_data(
         edge_index = get('edge_index')
     rowptr, col, pval, A = _get_P_csr(edge_index, n, edge_weight, row_normalize, dev)
     if graph_construction is not None:
-        A_vals = A.values()
+        A_vals = edge_weight                # what the reference leaves in data.edge_weight (:758): the coalesced weights
     _, blk = frames_and_Q(rowptr, col, pval, v, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
                           sing_vect_align_method, tikhonov_eps if rank_deficiency_strategy is not None else None)
     batch = {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk,

@@ -501,3 +501,43 @@ def test_sharded_dataset_build_equals_single_file(tmp_path):
                 x, y = fa[op][str(i)][d][...], fb[op][str(i)][d][...]
                 assert x.dtype == y.dtype and np.array_equal(x, y), (op, i, d)
     fa.close(); fb.close()
+
+
+def test_reweight_existing_edges_on_an_unsorted_edge_list_vs_reference_golden():
+    """graph_construction='reweight_existing_edges' keeps the reference's quirk -- the COALESCED weights
+    (row-major order) are what data.edge_weight receives, and get_P pairs them with the edge list in its original
+    order (process_pyg_data.py:758, :563-579).  Golden from the reference on a shuffled edge list
+    (tests/golden/make_round3b_goldens.py).  Duplicate edges: the reference fails, so does the drop-in."""
+    from esc_gnn_amd.process_pyg_data import process_pyg_data
+    _dev()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round3b_goldens.npz"))
+    pos, ei = g["rw_pos"], g["rw_ei"]
+    n = pos.shape[0]
+    key = ei[0] * n + ei[1]
+    assert not (key[1:] > key[:-1]).all()                                          # the point of the fixture
+    kw = {"r_cutoff": 5.0, "gaussian_eps": 4.0, "max_num_neighbors": 32}
+    data = _Data(pos=torch.from_numpy(pos), edge_index=torch.from_numpy(ei), num_nodes=n)
+    out = process_pyg_data(data, data_i=0, return_data_object=False, graph_construction="reweight_existing_edges",
+                           graph_construction_kwargs=kw, local_pca_kernel_fn_kwargs={"kernel": "epanechnikov", "r_cut": 5.0},
+                           hdf5_tensor_dtype="float32")
+    assert np.array_equal(out["edge_index"].numpy(), g["rw_edge_index"]) and np.array_equal(g["rw_edge_index"], ei)
+    assert np.abs(out["edge_weight"].numpy() - g["rw_edge_weight"]).max() <= 2e-7
+    assert np.array_equal(out["P"]["indices"].cpu().numpy(), g["rw_P_indices"])
+    assert np.abs(out["P"]["values"].cpu().numpy() - g["rw_P_values"]).max() <= 2e-7
+    assert np.array_equal(out["Q"]["indices"].cpu().numpy(), g["rw_Q_indices"])
+    # the weights aligned with the edges as given (what one might expect) would NOT reproduce the golden
+    d = np.linalg.norm(pos[ei[0]] - pos[ei[1]], axis=1)
+    w_aligned = np.exp(-(d / 4.0) ** 2) * 0.5 * (np.cos(np.pi * d / 5.0) + 1.0)
+    assert np.abs(w_aligned - g["rw_edge_weight"]).max() > 1e-3
+    # Q: p_ij times an orthogonal block everywhere; equal to the golden where the frames are well conditioned
+    ours, ref = _blocks(out["Q"]["values"].cpu().numpy()), _blocks(g["rw_Q_values"])
+    pv = g["rw_P_values"]
+    R = ours / pv[:, None, None]
+    assert np.abs(np.einsum("eab,ecb->eac", R, R) - np.eye(3)).max() <= 1e-5
+    err = np.abs(ours - ref).max(axis=(1, 2))
+    assert np.median(err) <= 1e-6 and (err <= 1e-4).mean() >= 0.9, (float(np.median(err)), float((err <= 1e-4).mean()))
+    dup = np.concatenate([ei, ei[:, :1]], axis=1)
+    with pytest.raises(ValueError):
+        process_pyg_data(_Data(pos=torch.from_numpy(pos), edge_index=torch.from_numpy(dup), num_nodes=n), data_i=0,
+                         return_data_object=False, graph_construction="reweight_existing_edges", graph_construction_kwargs=kw,
+                         local_pca_kernel_fn_kwargs={"kernel": "epanechnikov", "r_cut": 5.0}, hdf5_tensor_dtype="float32")
