@@ -67,6 +67,66 @@ def frames_and_Q(rowptr, col, pval, pos, kernel_kwargs, use_mean_recentering=Fal
     return frames, blk
 
 
+def _kernel_weights_torch(r: torch.Tensor, kw: Dict[str, Any]) -> torch.Tensor:
+    """get_local_pca_kernel_weights (process_pyg_data.py:79-138) as torch ops, for the generic-dimension path below"""
+    kw = dict(kw or {})
+    name, rc, eps = kw.get("kernel", "gaussian"), kw.get("r_cut"), kw.get("gaussian_eps")
+    _kernel_args(kw)                                  # the same argument errors as the d = 3 path
+    if name == "gaussian":
+        w = torch.exp(-r ** 2 / eps) if eps is not None else torch.exp(-r ** 2)
+        if rc is not None:
+            w = torch.where(r < rc, w, torch.zeros_like(w))
+    elif name == "cosine_cutoff":
+        w = torch.clamp(torch.where(r < rc, 0.5 * (torch.cos(math.pi * r / rc) + 1.0), torch.zeros_like(r)), min=0.0)
+    else:
+        w = torch.clamp(torch.where(r < rc, 1.0 - (r / rc) ** 2, torch.zeros_like(r)), min=0.0)
+    return torch.sqrt(w) if kw.get("take_sqrt", True) else w
+
+
+def frames_and_Q_any_dim(rowptr, col, pval, v, kernel_kwargs, use_mean_recentering=False, enforce_sign=True,
+                         sing_vect_align_method="column_dot", tikhonov_eps: Optional[float] = None):
+    """B2 + B3 for vector features of any dimension d (process_pyg_data.py:330-451 is dimension-generic; the theory
+    scripts use d = 2, theory_verification/vector_diffusion_equivariance_viz.py:322-395).  Not the hot path -- d = 3 has
+    its own kernels (frames_and_Q) -- so this is batched torch on the GPU: the left singular vectors of every node's
+    weighted neighbour matrix C_i (d x deg) as the eigenvectors of C_i C_i^T (fp64 eigh, descending; with the
+    reference's 'Tikhonov' branch, :262-279, the regularised covariance has the same eigenvectors), then
+    Q_ij = p_ij O_i S_ij O_j^T.  Column signs of a frame differ from LAPACK's SVD, which enforce_sign=True cancels
+    (both alignments are invariant to them); with enforce_sign=False the blocks depend on LAPACK's sign choice: unpinned.
+    Returns (frames (n, d, d), blk (nnz, d, d))."""
+    dev = v.device
+    n, d = v.shape
+    rp = rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+    cols = col.long()
+    off = rows != cols
+    er, ec = rows[off], cols[off]
+    deg = torch.bincount(er, minlength=n)
+    if bool((deg == 0).any()):
+        raise KeyError(f"{int((deg == 0).sum())} node(s) have no neighbours: the reference cannot build a frame for them "
+                       "(process_pyg_data.py:62-73, :823-826)")
+    if use_mean_recentering:                          # mean over the node and its neighbours (:64-67)
+        mu = (torch.zeros(n, d, device=dev).index_add_(0, er, v[ec]) + v) / (deg + 1).to(v.dtype)[:, None]
+        V = v[ec] - mu[er]
+    else:
+        V = v[ec] - v[er]
+    w = _kernel_weights_torch(V.norm(dim=1), kernel_kwargs)
+    WV = (w[:, None] * V).double()
+    cov = torch.zeros(n, d, d, dtype=torch.float64, device=dev).index_add_(0, er, WV[:, :, None] * WV[:, None, :])
+    if tikhonov_eps is not None:
+        cov = cov + float(tikhonov_eps) * torch.eye(d, dtype=torch.float64, device=dev)
+    O = torch.linalg.eigh(cov)[1].flip(-1).to(torch.float32).contiguous()          # columns by descending singular value
+    Oi, Oj = O[rows], O[cols]
+    if enforce_sign:
+        if sing_vect_align_method == "procrustes":                                # :296-304
+            U, _, Vt = torch.linalg.svd(Oi.transpose(1, 2) @ Oj, full_matrices=False)
+            Oj = Oj @ (U @ Vt)
+        else:                                                                      # column_dot (:306-313)
+            sgn = torch.where((Oi * Oj).sum(1) >= 0.0, 1.0, -1.0)
+            Oj = Oj * sgn[:, None, :]
+    blk = pval[:, None, None] * (Oi @ Oj.transpose(1, 2))
+    return O, blk.contiguous()
+
+
 def _knn_P_grid_batch(pos, gp, k, lib, dev):
     """escat_build_knn_P_grid per cloud (any size), results joined with global column ids."""
     rps, cols, vals, base = [], [], [], 0
@@ -175,12 +235,13 @@ def coo_parts(batch: Dict[str, Any], g: int, hdf5_tensor_dtype: str = "float16")
     rows = torch.repeat_interleave(torch.arange(n, device=rp.device), rp[1:] - rp[:-1])
     cols = batch["col"][e0:e1].long() - r0
     tdt = getattr(torch, hdf5_tensor_dtype)
-    a = torch.arange(3, device=rp.device)
-    qi = torch.stack([((3 * rows)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1),
-                      ((3 * cols)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1)])
+    d = int(batch["blk"].shape[1])                      # 3 on the hot path; any d from frames_and_Q_any_dim
+    a = torch.arange(d, device=rp.device)
+    qi = torch.stack([((d * rows)[:, None, None] + a[None, :, None] + 0 * a[None, None, :]).reshape(-1),
+                      ((d * cols)[:, None, None] + 0 * a[None, :, None] + a[None, None, :]).reshape(-1)])
     return {"original_idx": g,
             "P": {"indices": torch.stack([rows, cols]), "values": batch["pval"][e0:e1].to(tdt), "size": torch.Size([n, n])},
-            "Q": {"indices": qi, "values": batch["blk"][e0:e1].reshape(-1).to(tdt), "size": torch.Size([3 * n, 3 * n])}}
+            "Q": {"indices": qi, "values": batch["blk"][e0:e1].reshape(-1).to(tdt), "size": torch.Size([d * n, d * n])}}
 
 
 def _get_P_csr(edge_index, n, edge_weight, row_normalize, dev):
@@ -241,8 +302,8 @@ def process_pyg_data(
     get = (lambda k: data[k]) if hasattr(data, "__getitem__") else (lambda k: getattr(data, k))
     v = get(vector_feat_key).to(dev, torch.float32).contiguous()
     n, d = v.shape
-    if d != 3:
-        raise NotImplementedError("escat: the vector track is built for d = 3")
+    if d < 1:
+        raise ValueError("escat: vector features need at least one component")
     edge_weight = getattr(data, "edge_weight", None)
     A_vals = None
     if graph_construction is not None:
@@ -295,14 +356,15 @@ def process_pyg_data(
     rowptr, col, pval, A = _get_P_csr(edge_index, n, edge_weight, row_normalize, dev)
     if graph_construction is not None:
         A_vals = edge_weight                # what the reference leaves in data.edge_weight (:758): the coalesced weights
-    _, blk = frames_and_Q(rowptr, col, pval, v, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
-                          sing_vect_align_method, tikhonov_eps if rank_deficiency_strategy is not None else None)
+    build = frames_and_Q if d == 3 else frames_and_Q_any_dim       # d = 3: the HIP kernels; any other d: batched torch on the GPU
+    _, blk = build(rowptr, col, pval, v, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
+                   sing_vect_align_method, tikhonov_eps if rank_deficiency_strategy is not None else None)
     batch = {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk,
              "graph_ptr": torch.tensor([0, n], dtype=torch.int32)}
     parts = coo_parts(batch, 0, hdf5_tensor_dtype if not return_data_object else "float32")
     if return_data_object:
         P = torch.sparse_coo_tensor(parts["P"]["indices"], parts["P"]["values"], (n, n)).coalesce()
-        Q = torch.sparse_coo_tensor(parts["Q"]["indices"], parts["Q"]["values"], (3 * n, 3 * n))
+        Q = torch.sparse_coo_tensor(parts["Q"]["indices"], parts["Q"]["values"], (d * n, d * n))
         # an ESCGNNData (:870-882) carrying every attribute of `data` plus the operators; P and Q are the reference's
         # torch sparse tensors, with the canonical device form already attached (get_Batch_Wjxs skips the ingest)
         from .data_classes import ESCGNNData
@@ -311,7 +373,8 @@ def process_pyg_data(
         if graph_construction is not None:
             out.edge_index, out.edge_weight = edge_index, A_vals
         P._escat_operator = ScatterOperator.from_csr(rowptr, col, pval, n, validate=False)
-        Q._escat_operator = ScatterOperator.from_bsr3(rowptr, col, blk, n, validate=False)
+        if d == 3:                                      # (any other d: get_Batch_Wjxs ingests the COO as a scalar operator)
+            Q._escat_operator = ScatterOperator.from_bsr3(rowptr, col, blk, n, validate=False)
         out.P, out.Q = P, Q
         return out
     parts["original_idx"] = data_i
