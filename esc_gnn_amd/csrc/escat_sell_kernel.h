@@ -798,9 +798,13 @@ static int launch_sell_k2(const int *ci, const float *v, int n_parts, int max_ro
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, NT, lds) != hipSuccess || per < 1) per = 1;
         cached_per_cu = per; cached_lds = lds; cached_dev = dev_now;
     }
-    int per_cu = cached_per_cu, stagger = 0;
-    if (const char *e = getenv("ESCAT_DBG_PER_CU")) { const int v2 = atoi(e); if (v2 > 0 && v2 < per_cu) per_cu = v2; }
-    if (const char *e = getenv("ESCAT_DBG_STAGGER")) stagger = atoi(e);       // 10-ns ticks; < 0: odd workgroups instead of the second half
+    // experiment knobs (tools/sweep_stagger.sh; DESIGN.md 3 "Round 3"), read once: ESCAT_DBG_PER_CU caps the resident
+    // workgroups per CU, ESCAT_DBG_STAGGER delays half of the workgroups at start (10-ns ticks; < 0: the odd ones)
+    static const int dbg_per_cu = getenv("ESCAT_DBG_PER_CU") ? atoi(getenv("ESCAT_DBG_PER_CU")) : 0;
+    static const int dbg_stagger = getenv("ESCAT_DBG_STAGGER") ? atoi(getenv("ESCAT_DBG_STAGGER")) : 0;
+    int per_cu = cached_per_cu;
+    const int stagger = dbg_stagger;
+    if (dbg_per_cu > 0 && dbg_per_cu < per_cu) per_cu = dbg_per_cu;
     const int64_t resident = (int64_t)per_cu * escat_cu_count();
     const int grid = (int)(n_parts < resident ? n_parts : resident);           // persistent: one wave of workgroups
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ci, v, sd, IN, RES, T, tab, F, n_parts, max_rows, early, stagger);

@@ -148,7 +148,7 @@ typedef struct {
      * NULL when half_val is given (lc is not read either, but must be non-NULL). */
     const void     *half_val;
     const uint32_t *half_aux;
-    /* Round 3, BSR-3 only, optional: val == NULL, half_val == NULL and ent_of_slot != NULL = "direct" -- no value pack at
+    /* ABI version 4, BSR-3 only, optional: val == NULL, half_val == NULL and ent_of_slot != NULL = "direct" -- no value pack at
      * all: the chain reads every row's blocks from the canonical blk array it is given anyway (entry rowptr[row] +
      * ent_of_slot[(doff_s + d) * 64 + lane] sits in slot d; -1 = a padded slot), following the plan of a pack with the
      * same pattern (P of the batch: lc / lane_meta / pos_of_row are that pack's).  For an operator that is used once:
@@ -278,7 +278,8 @@ int escat_sell_plan_slots(const int32_t *rowptr, const int32_t *col, const int32
 
 /* last error message of the calling thread ("" if none). */
 const char *escat_last_error(void);
-/* ABI version, bumped when a signature changes. */
+/* ABI version, bumped when a signature or a struct changes (4: escat_sell.ent_of_slot, escat_sell_dims.row_len_hist, the
+ * single-pass ingest entry points). */
 int escat_abi_version(void);
 
 /* Y = A X.  Replaces one torch.sparse.mm(P_sparse, Ptx) call
