@@ -17,8 +17,12 @@ gp = torch.arange(args.graphs + 1, dtype=torch.int32) * args.nodes
 kw = {"kernel": "gaussian", "gaussian_eps": 0.05}
 path = os.path.join(tempfile.mkdtemp(), "pq.h5")
 write_dataset_hdf5(path, pos[:args.nodes * 64], gp[:65], args.k, kw)            # warm-up
-t0 = time.perf_counter(); info = write_dataset_hdf5(path, pos, gp, args.k, kw); dt = time.perf_counter() - t0
-size = os.path.getsize(path)
-t0 = time.perf_counter(); store = load_operator_store(path, dev); torch.cuda.synchronize(); dl = time.perf_counter() - t0
-print(json.dumps({"graphs": args.graphs, "build_and_write_s": round(dt, 2), "graphs_per_s": round(args.graphs / dt),
-                  "file_MB": round(size / 1e6, 1), "load_store_s": round(dl, 2), "load_graphs_per_s": round(args.graphs / dl)}))
+res = {"graphs": args.graphs}
+for comp in ("gzip", None):      # gzip = the reference's create_dataset(..., compression='gzip') (the default); None = contiguous
+    t0 = time.perf_counter(); info = write_dataset_hdf5(path, pos, gp, args.k, kw, compression=comp); dt = time.perf_counter() - t0
+    size = os.path.getsize(path)
+    t0 = time.perf_counter(); store = load_operator_store(path, dev); torch.cuda.synchronize(); dl = time.perf_counter() - t0
+    res[str(comp)] = {"build_and_write_s": round(dt, 2), "graphs_per_s": round(args.graphs / dt), "file_MB": round(size / 1e6, 1),
+                      "load_store_s": round(dl, 2), "load_graphs_per_s": round(args.graphs / dl)}
+    del store
+print(json.dumps(res))
