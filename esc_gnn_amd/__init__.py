@@ -17,5 +17,6 @@ from .operators import ScatterOperator, OperatorBatch, FactoredVectorOperator, a
 from .scales import ChainPlan, plan_chain                     # noqa: F401
 from .pyg_utilities import get_Batch_Wjxs                     # noqa: F401
 from .scatter import scatter, escat_scatter                   # noqa: F401
+from .both import get_Batch_Wjxs_both, BothTracksOperator     # noqa: F401
 from .invariants import get_vector_invariants                 # noqa: F401
 from .infogain import calc_infogain_wavelet_scales            # noqa: F401

@@ -53,6 +53,8 @@ SIGNATURES = {
     "escat_chain_csr_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_chain_bsr3_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
     "escat_chain_bsr3_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, vp, sz, vp]),
+    "escat_chain_both_f32": (ci, [vp, vp, vp, i64, i64, vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp]),
+    "escat_chain_both_bwd_f32": (ci, [vp, vp, vp, i64, i64, vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp]),
     "escat_scatter_orders_f32": (ci, [vp, vp, i64, ci, ci, vp, vp]),
     "escat_scatter_orders_bwd_f32": (ci, [vp, i64, vp, i64, ci, ci, vp, vp, vp]),
     "escat_sell_plan_slots": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]),

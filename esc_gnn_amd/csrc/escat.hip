@@ -1290,6 +1290,103 @@ extern "C" int escat_chain_csr_bwd_f32(const int32_t *rowptr_t, const int32_t *c
                            workspace, workspace_bytes, stream);
 }
 
+// ---- both tracks in one launch (escat_sell_both.hip)
+// The event table as a program of event steps; refuses (ESCAT_ERANGE: the caller runs the two chains separately) whatever
+// is not "every slot is one power or the difference of two, one band open at a time, the same for all channels".
+static int build_both_prog(const EvTable &tab, int T, int F, bool bwd, BothProg *pg)
+{
+    static thread_local signed char first_at[ESCAT_MAX_SLOTS], count[ESCAT_MAX_SLOTS];
+    for (int f = 0; f < F; ++f) { first_at[f] = -1; count[f] = 0; }
+    if (T > 127) return fail(ESCAT_ERANGE, "both-tracks chain: T=%d > 127", T);
+    for (int k = 0; k < tab.n; ++k) {
+        const Ev &e = tab.e[k];
+        if (e.chan >= 0) return fail(ESCAT_ERANGE, "both-tracks chain: per-channel events are not supported");
+        if (e.sign & EV_ABS) return fail(ESCAT_ERANGE, "both-tracks chain: ESCAT_EVENT_ABS is not supported");
+        if (++count[e.slot] > 2) return fail(ESCAT_ERANGE, "both-tracks chain: slot %d has more than two events", e.slot);
+        if (count[e.slot] == 1) first_at[e.slot] = (signed char)e.step;
+        else if (first_at[e.slot] == e.step) return fail(ESCAT_ERANGE, "both-tracks chain: slot %d takes the same power twice", e.slot);
+    }
+    pg->n = 0;
+    int open_slot = -1;
+    for (int k = 0; k < tab.n;) {
+        int k1 = k;
+        while (k1 < tab.n && tab.e[k1].step == tab.e[k].step) ++k1;
+        if (pg->n >= BOTH_MAX_STEPS) return fail(ESCAT_ERANGE, "both-tracks chain: more than %d steps with events", BOTH_MAX_STEPS);
+        if (k1 - k > (bwd ? 2 : BOTH_MAX_TERMS)) return fail(ESCAT_ERANGE, "both-tracks chain: %d events at step %d", k1 - k, tab.e[k].step);
+        BothStep &st = pg->s[pg->n++];
+        st.step = tab.e[k].step; st.n = k1 - k;
+        int closes = 0, opens = 0, directs = 0, opened = -1;
+        for (int j = k; j < k1; ++j) {
+            const Ev &e = tab.e[j];
+            int role;
+            if (count[e.slot] == 1) { role = 2; ++directs; }
+            else if (e.sign & EV_STORE) { role = 0; ++opens; opened = e.slot; }
+            else {
+                role = 1; ++closes;
+                if (open_slot != e.slot) return fail(ESCAT_ERANGE, "both-tracks chain: slot %d closes while slot %d is open", e.slot, open_slot);
+                open_slot = -1;
+            }
+            st.t[j - k].slot = (short)e.slot;
+            st.t[j - k].kind = (short)(role | ((e.sign & 2) ? 4 : 0));
+        }
+        if (closes > 1 || opens > 1 || directs > 1) return fail(ESCAT_ERANGE, "both-tracks chain: step %d has two events of a kind", st.step);
+        if (opens) {
+            if (open_slot >= 0) return fail(ESCAT_ERANGE, "both-tracks chain: two bands open at step %d", st.step);
+            open_slot = opened;
+        }
+        k = k1;
+    }
+    if (open_slot >= 0) return fail(ESCAT_EINVAL, "both-tracks chain: slot %d never closes", open_slot);
+    return ESCAT_OK;
+}
+
+template <bool BWD>
+static int chain_both(const int32_t *rowptr, const int32_t *col_signed, const float *mag, int64_t n, int64_t nnz,
+                      const float *INs, const float *INv, int T, const escat_event *events, int n_events, int F,
+                      float *RESs, float *RESv, const int32_t *part_ptr, int n_parts, int max_part_rows,
+                      const escat_sell *sell, void *stream)
+{
+    int rc = check_csr(rowptr, col_signed, mag, n, nnz); if (rc) return rc;
+    if (!INs || !INv || !RESs || !RESv) return fail(ESCAT_EINVAL, "input or output pointer is NULL");
+    if (T < 1) return fail(ESCAT_ERANGE, "both-tracks chain: T=%d < 1", T);
+    if (!sell || !sell->val || sell->val_planes != 4 || !sell->frames || sell->layout != 1 || !sell->pos_of_row)
+        return fail(ESCAT_EINVAL, "both-tracks chain: needs a sign-bit pack (val_planes = 4, layout 1) with frames and pos_of_row");
+    if (sell->orders) return fail(ESCAT_EINVAL, "both-tracks chain: escat_sell.orders must be 0");
+    if (!part_ptr || n_parts <= 0 || max_part_rows <= 0 || max_part_rows > 512)
+        return fail(ESCAT_ERANGE, "both-tracks chain: parts of 1..512 rows (got max %d)", max_part_rows);
+    if ((int64_t)n * 3 * F >= ((int64_t)1 << 31)) return fail(ESCAT_ERANGE, "both-tracks chain: n * 3 * F >= 2^31");
+    EvTable tab;
+    rc = build_table(events, n_events, T, F, 3, &tab, BWD); if (rc) return rc;
+    BothProg pg;
+    rc = build_both_prog(tab, T, F, BWD, &pg); if (rc) return rc;
+    if (n == 0) return ESCAT_OK;
+    SellDev sd;
+    rc = sell_to_dev(sell, &sd); if (rc) return rc;
+    rc = escat_launch_both_sell(BWD, max_part_rows, col_signed, mag, sd.part_list ? sell->n_list : n_parts, sd, INs, INv, RESs, RESv,
+                                T, pg, F, S(stream));
+    if (rc) return rc;
+    CHECK_LAUNCH("k_chain_both");
+    return ESCAT_OK;
+}
+
+extern "C" int escat_chain_both_f32(const int32_t *rowptr, const int32_t *col_signed, const float *mag, int64_t n, int64_t nnz,
+                                    const float *Xs, const float *Xv, int T, const escat_event *events, int n_events, int F,
+                                    float *OUTs, float *OUTv, const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                    const escat_sell *sell, void *stream)
+{
+    return chain_both<false>(rowptr, col_signed, mag, n, nnz, Xs, Xv, T, events, n_events, F, OUTs, OUTv, part_ptr, n_parts,
+                             max_part_rows, sell, stream);
+}
+
+extern "C" int escat_chain_both_bwd_f32(const int32_t *rowptr_t, const int32_t *col_signed_t, const float *mag_t, int64_t n, int64_t nnz,
+                                        const float *Gs, const float *Gv, int T, const escat_event *events, int n_events, int F,
+                                        float *dXs, float *dXv, const int32_t *part_ptr, int n_parts, int max_part_rows,
+                                        const escat_sell *sell, void *stream)
+{
+    return chain_both<true>(rowptr_t, col_signed_t, mag_t, n, nnz, Gs, Gv, T, events, n_events, F, dXs, dXv, part_ptr, n_parts,
+                            max_part_rows, sell, stream);
+}
+
 template <bool BWD>
 static int chain_bsr3(const int32_t *rowptr, const int32_t *col, const float *blk, int64_t nb, int64_t nnzb,
                       const float *IN, int T, const escat_event *events, int n_events, int F, float *RES,

@@ -162,4 +162,17 @@ __attribute__((visibility("hidden"))) int escat_launch_csr_sell_c56(bool bwd, in
 __attribute__((visibility("hidden"))) int escat_launch_csr_sell_c78(bool bwd, int C, ESCAT_SELL_ARGS);
 __attribute__((visibility("hidden"))) int escat_launch_csrv3_sell(bool bwd, ESCAT_SELL_ARGS);
 __attribute__((visibility("hidden"))) int escat_launch_bsr3h_sell(bool bwd, ESCAT_SELL_ARGS);
+
+// both tracks in one launch (escat_sell_both.hip): the event table as a program of event steps.  A term's kind: role
+// (0 = the band that opens at this step: hold <- +-y; 1 = the open band closes: OUT[slot] = hold +- y; 2 = a slot that is a
+// single power: OUT[slot] = +-y) | 4 if the power enters negatively.  Terms are in the caller's event order (the backward
+// adds the gradients in that order, as apply_events does).
+struct BothTerm { short slot, kind; };
+#define BOTH_MAX_STEPS 24
+#define BOTH_MAX_TERMS 3
+struct BothStep { int step, n; BothTerm t[BOTH_MAX_TERMS]; };
+struct BothProg { int n; BothStep s[BOTH_MAX_STEPS]; };
+__attribute__((visibility("hidden"))) int escat_launch_both_sell(bool bwd, int max_rows, const int *colw, const float *mag, int n_parts,
+                                                                 const SellDev &sd, const float *INs, const float *INv, float *RESs,
+                                                                 float *RESv, int T, const BothProg &prog, int F, hipStream_t st);
 #endif

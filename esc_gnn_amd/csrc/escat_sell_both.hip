@@ -1,0 +1,400 @@
+// escat_sell_both.hip -- BOTH tracks of ESCGNNModular.forward (models/escgnn_modular.py:674 scalar, :685 vector: two
+// _scatter calls, each a get_Batch_Wjxs chain, pyg_utilities.py:350-385) in ONE register-resident launch, for a batch
+// whose vector operator has the factored form Q = D Pt D^T on P's own pattern with |Pt_ij| = P_ij (what process_pyg_data
+// builds, process_pyg_data.py:306-313, :492, :823-857).
+//
+// Why (round 3, measured): a step of the P kernel and of the factored-Q kernel is ~45 % fixed latency (the chain
+// "last gather -> FMA -> vector stores -> their completion -> barrier -> first gather", ~1200 cycles per workgroup and
+// step at cfg2, tools/exp_imbalance.py: 2.0 us fixed + 0.2 us per slot) and both kernels run the SAME gathers on the same
+// plan.  Here one thread serves its row for both tracks: one address per slot feeds two ds_read_b128 (the second through
+// the instruction's immediate offset), one barrier and one latency chain per step carry twice the work, the operator is
+// streamed once (|p| + the slot's LDS row with three sign bits = 6 B per nonzero for both tracks).
+// What made the fusion lose on paper before ("both tracks in one launch -- priced, not built") was LDS: two
+// tracks' vectors AND a six-channel output slab need 152 KB = one workgroup per CU.  This kernel has NO slab: the owner
+// of a row keeps the one open band of each track in registers (6 floats) and writes every finished band straight to its
+// place in OUT (forward), and reads the upstream gradient of a step's events straight from G one gather phase ahead
+// (backward).  LDS is the four vectors (two tracks x ping-pong, two copies each) + the staged x: 80 KB, two workgroups
+// per CU as before.
+//
+// Registers per slot: v = +-|p| (sign = the vector track's channel 0; the scalar track multiplies by |v|, a free source
+// modifier) and u = 16 * LDS row | relative signs of channels 1, 2 as the top bits of bytes 2 and 3, which one SDWA
+// byte-xor each moves into the gathered x before the FMA.  The scalar track's FMAs run in OpCsr's order and the vector
+// track's in OpCsrV3's, the rotations use rotate_rows' / frame_to_global's formulas: both banks are BIT-IDENTICAL to what
+// the two separate launches give on the same values (tested).
+//
+// Event tables: the shared-scales plans (every slot = one power, or the difference of two powers; at most one band open
+// at a time) -- all of the drop-in's dyadic / custom-scale banks.  escat.hip turns the table into a BothProg and refuses
+// anything else (per-channel scales, |.| banks): the caller then runs the two chains separately.
+#include "escat_sell_kernel.h"
+
+template <int OFF> __device__ __forceinline__ void lds_gather_at(vf4 &d, unsigned a)
+{ asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
+template <int OFF> __device__ __forceinline__ void lds_store_at(unsigned a, const vf4 &v)
+{ asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory"); }
+// x <- x with its sign flipped iff the top bit of byte B of u is set (bytes 2 / 3 of OpBoth::u)
+template <int B> __device__ __forceinline__ float flip_by(float x, unsigned u)
+{
+    if (B == 2) asm("v_xor_b32_sdwa %0, %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_2" : "+v"(x) : "v"(u));
+    else        asm("v_xor_b32_sdwa %0, %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3" : "+v"(x) : "v"(u));
+    return x;
+}
+
+// a += |v| * x resp. a += v * x as single instructions: left to the compiler these become v_pk_fma_f32 on materialised
+// (|v|, |v|) and (v, v) register pairs -- 80 more live registers, all spilled
+__device__ __forceinline__ void fma_abs(float &a, float v, float x) { asm("v_fma_f32 %0, |%1|, %2, %0" : "+v"(a) : "v"(v), "v"(x)); }
+__device__ __forceinline__ void fma_one(float &a, float v, float x) { asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(a) : "v"(v), "v"(x)); }
+
+#ifndef ESCAT_BOTH_RING
+#define ESCAT_BOTH_RING 3
+#endif
+
+template <int DMAX, int VSTRIDE> struct OpBoth {
+    static constexpr int RING = ESCAT_BOTH_RING;  // slots in flight per lane (two gathers = 8 VGPRs each)
+    float v[DMAX];
+    unsigned u[DMAX];
+    // see OpBsr3::load for the unconditional burst; sd.val = the magnitudes, sd.lc = P's LDS rows with the sign bits
+    __device__ __forceinline__ void load(const SellDev &sd, int doff, int poff, int w, int lane)
+    {
+        const int wl = w > 0 ? w - 1 : 0;
+        const int pl = w > 0 ? ((w + SLOT_GROUP - 1) / SLOT_GROUP) * (SLOT_GROUP / 2) - 1 : 0;
+        unsigned lc[DMAX / 2];
+#pragma unroll
+        for (int j2 = 0; j2 < DMAX / 2; ++j2)
+            lc[j2] = sd.lc[(int64_t)(poff + (j2 < pl ? j2 : pl)) * 64 + lane];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) v[d] = sd.val[(int64_t)(doff + (d < wl ? d : wl)) * 64 + lane];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+            const unsigned f = (d & 1) ? (lc[d / 2] >> 16) : (lc[d / 2] & 0xffffu);     // row | s0 << 11 | s1 << 12 | s2 << 13
+            v[d] = __uint_as_float(__float_as_uint(v[d]) | ((f << 20) & 0x80000000u));
+            const unsigned rel = f ^ (f >> 1), rel2 = f ^ (f >> 2);                    // bit 11: s0 ^ s1 resp. s0 ^ s2
+            u[d] = ((f & 0x7ffu) << 4) | ((rel << 12) & 0x00800000u) | ((rel2 << 20) & 0x80000000u);
+        }
+    }
+    __device__ __forceinline__ unsigned addr(int d, unsigned base) const
+    {
+        unsigned a;      // one VALU instruction the optimiser cannot take apart (see OpQH::gather_w)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a) : "v"(u[d]), "v"(base));
+        return a;
+    }
+    template <int W>
+    __device__ __forceinline__ void gather_w(unsigned base, float (&aP)[3], float (&aQ)[3]) const
+    {
+        constexpr int D = RING;
+        vf4 xp[D], xq[D];
+#pragma unroll
+        for (int d = 0; d < D && d < W; ++d) {
+            const unsigned a = addr(d, base);
+            lds_gather_at<0>(xp[d], a); lds_gather_at<VSTRIDE>(xq[d], a);
+        }
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            // both gathers of slot d have landed once at most 2 * min(D-1, W-1-d) younger LDS operations are outstanding
+            const int later = 2 * (W - 1 - d < D - 1 ? W - 1 - d : D - 1);
+            vf4 &last = xq[d % D];
+            if (later >= 8) lds_wait<8>(last);
+            else if (later == 6) lds_wait<6>(last);
+            else if (later == 4) lds_wait<4>(last);
+            else if (later == 2) lds_wait<2>(last);
+            else lds_wait<0>(last);
+            asm volatile("" : "+v"(xp[d % D]));               // the first gather landed before the second
+            const vf4 p = xp[d % D];
+            fma_abs(aP[0], v[d], p.x); fma_abs(aP[1], v[d], p.y); fma_abs(aP[2], v[d], p.z);
+            const vf4 q = xq[d % D];
+            const float q1 = flip_by<2>(q.y, u[d]), q2 = flip_by<3>(q.z, u[d]);
+            fma_one(aQ[0], v[d], q.x); fma_one(aQ[1], v[d], q1); fma_one(aQ[2], v[d], q2);
+            asm volatile("" :: "v"(p.w), "v"(q.w));           // keep the gathers ds_read_b128
+            if (d + D < W) {
+                asm volatile("" :: "v"(aP[0]), "v"(aP[1]), "v"(aP[2]), "v"(aQ[0]), "v"(aQ[1]), "v"(aQ[2]));     // see OpBsr3::gather_w
+                const unsigned a = addr(d + D, base);
+                lds_gather_at<0>(xp[d % D], a); lds_gather_at<VSTRIDE>(xq[d % D], a);
+            }
+        }
+    }
+    template <int W>
+    __device__ __forceinline__ void dispatch(int w2, unsigned base, float (&aP)[3], float (&aQ)[3]) const
+    {
+        if constexpr (W <= DMAX) {
+            if (w2 == W / 2) gather_w<W>(base, aP, aQ);
+            else dispatch<W + 2>(w2, base, aP, aQ);
+        }
+    }
+    __device__ __forceinline__ void gather(unsigned base, int w, float (&aP)[3], float (&aQ)[3]) const { dispatch<2>((w + 1) >> 1, base, aP, aQ); }
+};
+
+// entries beyond dmax (rare): from the global arrays in the packed form of k_csr_step<.., 4> (col | signs << 29, |value|)
+template <int VSTRIDE>
+__device__ __forceinline__ void both_tail(const float *__restrict__ mag, const int *__restrict__ colw, int e0, int n, const float *xa,
+                                          float (&aP)[3], float (&aQ)[3], const int *__restrict__ pos)
+{
+    for (int e = e0; e < e0 + n; ++e) {
+        const unsigned cw = (unsigned)colw[e], vb = __float_as_uint(mag[e]);
+        const float *xp = xa + pos[(int)(cw & 0x1fffffffu)] * 4, *xq = xp + VSTRIDE / 4;
+        const float m = __uint_as_float(vb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            aP[c] = fmaf(m, xp[c], aP[c]);
+            aQ[c] = fmaf(__uint_as_float(vb | ((cw << (2 - c)) & 0x80000000u)), xq[c], aQ[c]);
+        }
+    }
+}
+
+// LDS (bytes from the dynamic base): xaP | xaQ | xbP | xbQ, VSTRIDE each (two copies of <= NT + 16 rows of 16 B);
+// forward: + the staged x of both tracks (rows * 3 floats each); + the slice words of the next part (8 per wave)
+template <int DMAX, int NT, bool BWD>
+__global__ void __launch_bounds__(NT, 4)          // 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
+k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDev sd, const float *__restrict__ INs,
+             const float *__restrict__ INv, float *__restrict__ RESs, float *__restrict__ RESv, int T, BothProg prog, int F,
+             int n_parts, int max_rows)
+{
+    constexpr int VSTRIDE = 2 * (NT + 16) * 16;
+    extern __shared__ __align__(16) float smem[];
+    const unsigned lds0 = lds_addr(smem);
+    const int stage = (max_rows * 3 + 3) & ~3;
+    float *inbS = smem + 4 * (VSTRIDE / 4), *inbV = inbS + stage;            // forward only
+    int *metaS = reinterpret_cast<int *>(smem + 4 * (VSTRIDE / 4) + (BWD ? 0 : 2 * stage));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xr = threadIdx.x;
+    auto part_of = [&](int li_) { return sd.part_list ? sd.part_list[li_] : li_; };
+    auto dma_meta = [&](int part_) {                  // the slice words of a part's slices: every wave fetches and reads its own
+        if (lane < 8) {
+            const int *lm = sd.lane_meta + ((int64_t)(part_ * sd.nsl + wave) * 64 + lane) * 3 + 2;
+            __builtin_amdgcn_global_load_lds((glb_void_t *)lm, (lds_void_t *)(metaS + wave * 8), 4, 0, 0);
+        }
+    };
+    OpBoth<DMAX, VSTRIDE> op;
+    int li = blockIdx.x;
+    if (li >= n_parts) return;
+    int part = part_of(li);
+    dma_meta(part);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int sw = metaS[wave * 8 + (lane & 7)];
+    bool x_staged = false;
+    for (;;) {
+        const int doff = __builtin_amdgcn_readlane(sw, 0), poff = __builtin_amdgcn_readlane(sw, 1);
+        const int w = __builtin_amdgcn_readlane(sw, 2);
+        const int gs = __builtin_amdgcn_readlane(sw, 3), rows = __builtin_amdgcn_readlane(sw, 4);
+        const int row0 = sd.part_row0 ? sd.part_row0[li] : gs;
+        const int liN = li + gridDim.x;
+        const bool has_next = liN < n_parts;      // uniform
+        const int partN = has_next ? part_of(liN) : 0;
+        const int *lm = sd.lane_meta + ((int64_t)(part * sd.nsl + wave) * 64 + lane) * 3;
+        const int rt = lm[0], te0 = lm[1];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // sw is in registers: its LDS words are free
+        if (has_next) dma_meta(partN);
+        if (!BWD && !x_staged) {
+            dma_in<NT>(inbS, INs + (int64_t)row0 * 3, rows * 3);
+            dma_in<NT>(inbV, INv + (int64_t)row0 * 3, rows * 3);
+        }
+        asm volatile("" ::: "memory");
+        op.load(sd, doff, poff, w, lane);
+        const int r = (rt & 0x3ff) == 0x3ff ? -1 : (rt & 0x3ff);
+        const bool own = r >= 0;
+        const int tn = (int)((unsigned)rt >> 10);
+        const bool has_tail = __any(tn);          // wave-uniform, rare
+        float o[9];                               // the row's local frame, kept for the whole part (bands leave / gradients enter through it)
+        {
+            const float *fp = sd.frames + ((int64_t)gs + (own ? r : 0)) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = fp[k];
+        }
+        const int64_t orow = ((int64_t)row0 + (own ? r : 0)) * 3;              // first of the row's three (row, channel) lines in IN / RES
+        const unsigned offA = (unsigned)xr * 16u, offB = (unsigned)(sell_padR(rows) + sell_swzB(xr)) * 16u;
+        // ---- first vector of both tracks + the events of step 0 (forward) / of step T (backward)
+        float hP[3] = {0.f, 0.f, 0.f}, hQ[3] = {0.f, 0.f, 0.f};               // forward: the open band of each track
+        int p = 0;                                // cursor into prog.s (forward: next step to serve; backward: one past it)
+        float yP[3], yQ[3];
+        if (BWD) {
+            p = prog.n;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { yP[c] = 0.f; yQ[c] = 0.f; }
+            if (p > 0 && prog.s[p - 1].step == T) {
+                --p;
+                const int nt = prog.s[p].n;
+                for (int k = 0; k < nt; ++k) {
+                    const int slot = prog.s[p].t[k].slot; const bool neg = prog.s[p].t[k].kind & 4;
+                    float g[3], gv[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { g[c] = own ? INs[(orow + c) * F + slot] : 0.f; gv[c] = own ? INv[(orow + c) * F + slot] : 0.f; }
+                    const float t0 = fmaf(o[6], gv[2], fmaf(o[3], gv[1], o[0] * gv[0]));       // rotate_rows<true>
+                    const float t1 = fmaf(o[7], gv[2], fmaf(o[4], gv[1], o[1] * gv[0]));
+                    const float t2 = fmaf(o[8], gv[2], fmaf(o[5], gv[1], o[2] * gv[0]));
+                    yP[0] += neg ? -g[0] : g[0]; yP[1] += neg ? -g[1] : g[1]; yP[2] += neg ? -g[2] : g[2];
+                    yQ[0] += neg ? -t0 : t0; yQ[1] += neg ? -t1 : t1; yQ[2] += neg ? -t2 : t2;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                      // the previous part's last gathers are done: its vectors may be overwritten
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                      // every wave's x has landed
+            if (own) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) yP[c] = inbS[r * 3 + c];
+                const float x0 = inbV[r * 3], x1 = inbV[r * 3 + 1], x2 = inbV[r * 3 + 2];
+                yQ[0] = fmaf(o[6], x2, fmaf(o[3], x1, o[0] * x0));                              // rotate_rows<true>
+                yQ[1] = fmaf(o[7], x2, fmaf(o[4], x1, o[1] * x0));
+                yQ[2] = fmaf(o[8], x2, fmaf(o[5], x1, o[2] * x0));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { yP[c] = 0.f; yQ[c] = 0.f; }
+            }
+        }
+        // (the event handler of the forward: closes and single-power slots first, then the band that opens)
+        auto emit = [&](int ps) {
+            const int nt = prog.s[ps].n;
+            for (int k = 0; k < nt; ++k) {
+                const int kind = prog.s[ps].t[k].kind, slot = prog.s[ps].t[k].slot;
+                if ((kind & 3) == 0) continue;
+                float a[3], b[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { a[c] = (kind & 4) ? -yP[c] : yP[c]; b[c] = (kind & 4) ? -yQ[c] : yQ[c]; }
+                if ((kind & 3) == 1) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { a[c] += hP[c]; b[c] += hQ[c]; }
+                }
+                frame_to_global(b, o);
+                if (own) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { RESs[(orow + c) * F + slot] = a[c]; RESv[(orow + c) * F + slot] = b[c]; }
+                }
+            }
+            for (int k = 0; k < nt; ++k) {
+                const int kind = prog.s[ps].t[k].kind;
+                if ((kind & 3) != 0) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { hP[c] = (kind & 4) ? -yP[c] : yP[c]; hQ[c] = (kind & 4) ? -yQ[c] : yQ[c]; }
+            }
+        };
+        unsigned baseR = lds0, baseW = lds0 + 2 * VSTRIDE;
+        {
+            const vf4 vp = {yP[0], yP[1], yP[2], 0.f}, vq = {yQ[0], yQ[1], yQ[2], 0.f};
+            if (own) {
+                lds_store_at<0>(baseR + offA, vp); lds_store_at<0>(baseR + offB, vp);
+                lds_store_at<VSTRIDE>(baseR + offA, vq); lds_store_at<VSTRIDE>(baseR + offB, vq);
+            }
+            if (xr < 4) {                         // the all-zero row (target of padded slots), copy A of all four vectors
+                float *z = smem + rows * 4 + xr;
+                z[0] = 0.f; z[VSTRIDE / 4] = 0.f; z[2 * VSTRIDE / 4] = 0.f; z[3 * VSTRIDE / 4] = 0.f;
+            }
+            if (!BWD && prog.n > 0 && prog.s[0].step == 0) { emit(0); p = 1; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the next part: its slice words are here (the wait above covered them); forward: its x, now that inb is free
+        int swN = 0;
+        x_staged = false;
+        if (has_next) {
+            swN = metaS[wave * 8 + (lane & 7)];
+            if (!BWD) {
+                const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
+                const int64_t r0N = sd.part_row0 ? sd.part_row0[liN] : gsN;
+                dma_in<NT>(inbS, INs + r0N * 3, rowsN * 3);
+                dma_in<NT>(inbV, INv + r0N * 3, rowsN * 3);
+                x_staged = true;
+            }
+        }
+        for (int t = 1; t <= T; ++t) {
+            const int st = BWD ? T - t : t;
+            float g[2][6];                        // backward: the upstream gradient of this step's (<= 2) events, asked for now
+            int gn = 0;
+            bool gneg[2] = {false, false};
+            if (BWD && p > 0 && prog.s[p - 1].step == st) {
+                --p;
+                gn = prog.s[p].n;
+                for (int k = 0; k < 2; ++k) {
+                    if (k < gn) {
+                        const int slot = prog.s[p].t[k].slot;
+                        gneg[k] = prog.s[p].t[k].kind & 4;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { g[k][c] = own ? INs[(orow + c) * F + slot] : 0.f; g[k][3 + c] = own ? INv[(orow + c) * F + slot] : 0.f; }
+                    }
+                }
+            }
+            float aP[3] = {0.f, 0.f, 0.f}, aQ[3] = {0.f, 0.f, 0.f};
+            op.gather(baseR, w, aP, aQ);
+            if (has_tail && tn)
+                both_tail<VSTRIDE>(mag, colw, te0, tn, smem + (baseR - lds0) / 4, aP, aQ, sd.pos_of_row);
+            if (BWD) {
+                for (int k = 0; k < 2; ++k) {
+                    if (k < gn) {
+                        const float t0 = fmaf(o[6], g[k][5], fmaf(o[3], g[k][4], o[0] * g[k][3]));
+                        const float t1 = fmaf(o[7], g[k][5], fmaf(o[4], g[k][4], o[1] * g[k][3]));
+                        const float t2 = fmaf(o[8], g[k][5], fmaf(o[5], g[k][4], o[2] * g[k][3]));
+                        aP[0] += gneg[k] ? -g[k][0] : g[k][0]; aP[1] += gneg[k] ? -g[k][1] : g[k][1]; aP[2] += gneg[k] ? -g[k][2] : g[k][2];
+                        aQ[0] += gneg[k] ? -t0 : t0; aQ[1] += gneg[k] ? -t1 : t1; aQ[2] += gneg[k] ? -t2 : t2;
+                    }
+                }
+            }
+            {
+                const vf4 vp = {aP[0], aP[1], aP[2], 0.f}, vq = {aQ[0], aQ[1], aQ[2], 0.f};
+                if (own) {
+                    lds_store_at<0>(baseW + offA, vp); lds_store_at<0>(baseW + offB, vp);
+                    lds_store_at<VSTRIDE>(baseW + offA, vq); lds_store_at<VSTRIDE>(baseW + offB, vq);
+                }
+            }
+            if (!BWD) {
+                if (p < prog.n && prog.s[p].step == t) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { yP[c] = aP[c]; yQ[c] = aQ[c]; }
+                    emit(p); ++p;
+                }
+            } else if (t == T && own) {           // the owner holds the answer of its row: straight to HBM
+                frame_to_global(aQ, o);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { RESs[orow + c] = aP[c]; RESv[orow + c] = aQ[c]; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const unsigned tmp = baseR; baseR = baseW; baseW = tmp;
+        }
+        if (!has_next) break;
+        li = liN; part = partN; sw = swN;
+    }
+}
+
+template <int DMAX, int NT, bool BWD>
+static int launch_both2(const int *colw, const float *mag, int n_parts, int max_rows, const SellDev &sd, const float *INs,
+                        const float *INv, float *RESs, float *RESv, int T, const BothProg &prog, int F, hipStream_t st)
+{
+    const size_t lds = (size_t)4 * 2 * (NT + 16) * 16 + (BWD ? 0 : 2 * (size_t)((max_rows * 3 + 3) & ~3) * 4) + (NT / 64) * 8 * sizeof(int);
+    if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "both-tracks chain needs %zu B of LDS", lds);
+    auto kern = k_chain_both<DMAX, NT, BWD>;
+    int rc = set_lds(kern, lds); if (rc) return rc;
+    static thread_local size_t cached_lds = (size_t)-1; static thread_local int cached_per_cu = 0, cached_dev = -1;
+    int dev_now = 0;
+    (void)hipGetDevice(&dev_now);
+    if (cached_lds != lds || cached_dev != dev_now) {
+        int per = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, NT, lds) != hipSuccess || per < 1) per = 1;
+        cached_per_cu = per; cached_lds = lds; cached_dev = dev_now;
+    }
+    static const int dbg_per_cu = getenv("ESCAT_DBG_PER_CU") ? atoi(getenv("ESCAT_DBG_PER_CU")) : 0;
+    int per_cu = cached_per_cu;
+    if (dbg_per_cu > 0 && dbg_per_cu < per_cu) per_cu = dbg_per_cu;
+    const int64_t resident = (int64_t)per_cu * escat_cu_count();
+    const int grid = (int)(n_parts < resident ? n_parts : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, colw, mag, sd, INs, INv, RESs, RESv, T, prog, F, n_parts, max_rows);
+    return ESCAT_OK;
+}
+
+template <int DMAX, bool BWD>
+static int launch_both_d(int max_rows, const int *colw, const float *mag, int n_parts, const SellDev &sd, const float *INs,
+                         const float *INv, float *RESs, float *RESv, int T, const BothProg &prog, int F, hipStream_t st)
+{
+    const int NT = max_rows <= 256 ? 256 : 512;
+    if (sd.nsl * 64 != NT) return fail(ESCAT_EINVAL, "escat_sell.slices_per_part=%d does not match parts of <= %d rows", sd.nsl, max_rows);
+    if (NT == 256) return launch_both2<DMAX, 256, BWD>(colw, mag, n_parts, max_rows, sd, INs, INv, RESs, RESv, T, prog, F, st);
+    return launch_both2<DMAX, 512, BWD>(colw, mag, n_parts, max_rows, sd, INs, INv, RESs, RESv, T, prog, F, st);
+}
+
+int escat_launch_both_sell(bool bwd, int max_rows, const int *colw, const float *mag, int n_parts, const SellDev &sd,
+                           const float *INs, const float *INv, float *RESs, float *RESv, int T, const BothProg &prog, int F,
+                           hipStream_t st)
+{
+    switch (sd.dmax) {
+#define CASE(d) case d: return bwd ? launch_both_d<d, true>(max_rows, colw, mag, n_parts, sd, INs, INv, RESs, RESv, T, prog, F, st) \
+                                   : launch_both_d<d, false>(max_rows, colw, mag, n_parts, sd, INs, INv, RESs, RESv, T, prog, F, st);
+        CASE(8) CASE(16) CASE(20) CASE(24)
+#undef CASE
+    }
+    return fail(ESCAT_EINVAL, "escat_sell.dmax=%d: per-channel CSR packs must use 8, 16, 20 or 24", sd.dmax);
+}

@@ -365,6 +365,34 @@ int escat_chain_bsr3_bwd_f32(const int32_t *rowptr_t, const int32_t *col_t, cons
                              const int32_t *part_ptr, int n_parts, int max_part_rows, const escat_sell *sell,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* BOTH tracks of a batch in one launch (round 3).  ESCGNNModular.forward runs _scatter twice per batch -- scalar track on
+ * P (models/escgnn_modular.py:674), vector track on Q (:685) -- i.e. two get_Batch_Wjxs chains (pyg_utilities.py:350-385) on
+ * one pattern.  When Q has the factored form Q = D Pt D^T (escat_sell.frames, val_planes = 4) AND |Pt_ij| = P_ij -- what
+ * process_pyg_data builds (process_pyg_data.py:306-313, :492, :823-857) -- one thread serves its row for both tracks: the
+ * operator is streamed once, every step costs one barrier and one LDS latency chain instead of two.
+ *   rowptr / col_signed / mag   the signed operator's global arrays (col | signs << 29, |value| = P's values >= 0); only
+ *                               rows longer than the pack's capacity read them
+ *   Xs (n, 3)                   scalar-track input; the scalar track uses |value|, i.e. P itself
+ *   Xv (n, 3)                   vector-track input = the (3n,) flattening of the node vectors, global coordinates
+ *   OUTs, OUTv (n, 3, F)        the two banks ((3n, 1, F) for the vector track), as the two separate entry points write
+ *                               them -- bit for bit (same arithmetic, same order)
+ *   sell                        the sign-bit pack (val_planes = 4, layout 1, frames, pos_of_row), orders = 0; part_list
+ *                               views are honoured
+ * Register-resident path only (parts of <= 512 rows); event tables in which every slot is one power or the difference of
+ * two powers, with at most one difference open at a time and no per-channel or ESCAT_EVENT_ABS events (all shared-scale
+ * banks of get_Batch_Wjxs).  Anything else returns ESCAT_ERANGE and the caller runs the two chains separately.  The
+ * kernel holds no output slab in LDS: finished bands go from registers straight to OUT. */
+int escat_chain_both_f32(const int32_t *rowptr, const int32_t *col_signed, const float *mag, int64_t n, int64_t nnz,
+                         const float *Xs, const float *Xv, int T, const escat_event *events, int n_events, int F,
+                         float *OUTs, float *OUTv, const int32_t *part_ptr, int n_parts, int max_part_rows,
+                         const escat_sell *sell, void *stream);
+/* its backward: the TRANSPOSED signed operator (pack, global arrays), upstream gradients Gs, Gv (n, 3, F) -> dXs, dXv (n, 3);
+ * at most two events per step. */
+int escat_chain_both_bwd_f32(const int32_t *rowptr_t, const int32_t *col_signed_t, const float *mag_t, int64_t n, int64_t nnz,
+                             const float *Gs, const float *Gv, int T, const escat_event *events, int n_events, int F,
+                             float *dXs, float *dXv, const int32_t *part_ptr, int n_parts, int max_part_rows,
+                             const escat_sell *sell, void *stream);
+
 /* Orders 0/1/2 of ESCGNNModular._scatter (models/escgnn_modular.py:333-341,
  * :355-360): W (rows, Wtot) = [x0 | W1 | W1[i]*W1[j] for i<j in triu order
  * (:507-516)], Wtot = 1 + F + (second_order ? F(F-1)/2 : 0).  rows = n*C. */
