@@ -1326,8 +1326,8 @@ static int build_both_prog(const EvTable &tab, int T, int F, bool bwd, BothProg 
                 if (open_slot != e.slot) return fail(ESCAT_ERANGE, "both-tracks chain: slot %d closes while slot %d is open", e.slot, open_slot);
                 open_slot = -1;
             }
-            st.t[j - k].slot = (short)e.slot;
-            st.t[j - k].kind = (short)(role | ((e.sign & 2) ? 4 : 0));
+            st.t[j - k].slot = e.slot;
+            st.t[j - k].kind = role | ((e.sign & 2) ? 4 : 0);
         }
         if (closes > 1 || opens > 1 || directs > 1) return fail(ESCAT_ERANGE, "both-tracks chain: step %d has two events of a kind", st.step);
         if (opens) {

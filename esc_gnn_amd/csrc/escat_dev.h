@@ -167,7 +167,7 @@ __attribute__((visibility("hidden"))) int escat_launch_bsr3h_sell(bool bwd, ESCA
 // (0 = the band that opens at this step: hold <- +-y; 1 = the open band closes: OUT[slot] = hold +- y; 2 = a slot that is a
 // single power: OUT[slot] = +-y) | 4 if the power enters negatively.  Terms are in the caller's event order (the backward
 // adds the gradients in that order, as apply_events does).
-struct BothTerm { short slot, kind; };
+struct BothTerm { int slot, kind; };       // (ints: scalar loads; shorts come through vector memory and its counter)
 #define BOTH_MAX_STEPS 24
 #define BOTH_MAX_TERMS 3
 struct BothStep { int step, n; BothTerm t[BOTH_MAX_TERMS]; };

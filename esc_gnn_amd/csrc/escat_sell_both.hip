@@ -27,6 +27,7 @@
 // anything else (per-channel scales, |.| banks): the caller then runs the two chains separately.
 #include "escat_sell_kernel.h"
 
+struct __attribute__((packed, aligned(4))) f2u_k { float x, y; };      // an 8-byte access that is only dword-aligned
 template <int OFF> __device__ __forceinline__ void lds_gather_at(vf4 &d, unsigned a)
 { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF)); }
 template <int OFF> __device__ __forceinline__ void lds_store_at(unsigned a, const vf4 &v)
@@ -46,6 +47,9 @@ __device__ __forceinline__ void fma_one(float &a, float v, float x) { asm("v_fma
 
 #ifndef ESCAT_BOTH_RING
 #define ESCAT_BOTH_RING 3
+#endif
+#ifndef ESCAT_BOTH_EXP     // timing experiments only (results wrong): 1 no sign flips, 2 no vector-track gathers / FMAs,
+#define ESCAT_BOTH_EXP 0   // 4 no global event traffic, 8 no scalar-track FMAs, 16 no band write-out at all
 #endif
 
 template <int DMAX, int VSTRIDE> struct OpBoth {
@@ -85,29 +89,35 @@ template <int DMAX, int VSTRIDE> struct OpBoth {
 #pragma unroll
         for (int d = 0; d < D && d < W; ++d) {
             const unsigned a = addr(d, base);
-            lds_gather_at<0>(xp[d], a); lds_gather_at<VSTRIDE>(xq[d], a);
+            lds_gather_at<0>(xp[d], a); if (!(ESCAT_BOTH_EXP & 2)) lds_gather_at<VSTRIDE>(xq[d], a);
         }
 #pragma unroll
         for (int d = 0; d < W; ++d) {
             // both gathers of slot d have landed once at most 2 * min(D-1, W-1-d) younger LDS operations are outstanding
-            const int later = 2 * (W - 1 - d < D - 1 ? W - 1 - d : D - 1);
-            vf4 &last = xq[d % D];
+            const int later = ((ESCAT_BOTH_EXP & 2) ? 1 : 2) * (W - 1 - d < D - 1 ? W - 1 - d : D - 1);
+            vf4 &last = (ESCAT_BOTH_EXP & 2) ? xp[d % D] : xq[d % D];
             if (later >= 8) lds_wait<8>(last);
             else if (later == 6) lds_wait<6>(last);
             else if (later == 4) lds_wait<4>(last);
+            else if (later == 3) lds_wait<3>(last);
             else if (later == 2) lds_wait<2>(last);
+            else if (later == 1) lds_wait<1>(last);
             else lds_wait<0>(last);
             asm volatile("" : "+v"(xp[d % D]));               // the first gather landed before the second
             const vf4 p = xp[d % D];
-            fma_abs(aP[0], v[d], p.x); fma_abs(aP[1], v[d], p.y); fma_abs(aP[2], v[d], p.z);
-            const vf4 q = xq[d % D];
-            const float q1 = flip_by<2>(q.y, u[d]), q2 = flip_by<3>(q.z, u[d]);
-            fma_one(aQ[0], v[d], q.x); fma_one(aQ[1], v[d], q1); fma_one(aQ[2], v[d], q2);
-            asm volatile("" :: "v"(p.w), "v"(q.w));           // keep the gathers ds_read_b128
+            if (!(ESCAT_BOTH_EXP & 8)) { fma_abs(aP[0], v[d], p.x); fma_abs(aP[1], v[d], p.y); fma_abs(aP[2], v[d], p.z); }
+            else asm volatile("" :: "v"(p.x));
+            if (!(ESCAT_BOTH_EXP & 2)) {
+                const vf4 q = xq[d % D];
+                const float q1 = (ESCAT_BOTH_EXP & 1) ? q.y : flip_by<2>(q.y, u[d]), q2 = (ESCAT_BOTH_EXP & 1) ? q.z : flip_by<3>(q.z, u[d]);
+                fma_one(aQ[0], v[d], q.x); fma_one(aQ[1], v[d], q1); fma_one(aQ[2], v[d], q2);
+                asm volatile("" :: "v"(q.w));
+            }
+            asm volatile("" :: "v"(p.w));                     // keep the gathers ds_read_b128
             if (d + D < W) {
                 asm volatile("" :: "v"(aP[0]), "v"(aP[1]), "v"(aP[2]), "v"(aQ[0]), "v"(aQ[1]), "v"(aQ[2]));     // see OpBsr3::gather_w
                 const unsigned a = addr(d + D, base);
-                lds_gather_at<0>(xp[d % D], a); lds_gather_at<VSTRIDE>(xq[d % D], a);
+                lds_gather_at<0>(xp[d % D], a); if (!(ESCAT_BOTH_EXP & 2)) lds_gather_at<VSTRIDE>(xq[d % D], a);
             }
         }
     }
@@ -140,7 +150,8 @@ __device__ __forceinline__ void both_tail(const float *__restrict__ mag, const i
 }
 
 // LDS (bytes from the dynamic base): xaP | xaQ | xbP | xbQ, VSTRIDE each (two copies of <= NT + 16 rows of 16 B);
-// forward: + the staged x of both tracks (rows * 3 floats each); + the slice words of the next part (8 per wave)
+// forward: + the stage (rows * 3 floats per track: the part's x until the prologue, then one finished band at a time on
+// its way out); + the slice words of the next part (8 per wave)
 template <int DMAX, int NT, bool BWD>
 __global__ void __launch_bounds__(NT, 4)          // 128 VGPRs: two 512-thread (four 256-thread) workgroups per CU
 k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDev sd, const float *__restrict__ INs,
@@ -169,7 +180,6 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
     dma_meta(part);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int sw = metaS[wave * 8 + (lane & 7)];
-    bool x_staged = false;
     for (;;) {
         const int doff = __builtin_amdgcn_readlane(sw, 0), poff = __builtin_amdgcn_readlane(sw, 1);
         const int w = __builtin_amdgcn_readlane(sw, 2);
@@ -182,7 +192,7 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         const int rt = lm[0], te0 = lm[1];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // sw is in registers: its LDS words are free
         if (has_next) dma_meta(partN);
-        if (!BWD && !x_staged) {
+        if (!BWD) {                               // (the stage is free: the previous part's last band left behind a barrier)
             dma_in<NT>(inbS, INs + (int64_t)row0 * 3, rows * 3);
             dma_in<NT>(inbV, INv + (int64_t)row0 * 3, rows * 3);
         }
@@ -192,7 +202,10 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         const bool own = r >= 0;
         const int tn = (int)((unsigned)rt >> 10);
         const bool has_tail = __any(tn);          // wave-uniform, rare
-        float o[9];                               // the row's local frame, kept for the whole part (bands leave / gradients enter through it)
+        // the row's local frame.  Backward: kept for the whole part (gradients enter and the answer leaves through it).
+        // Forward: only the prologue's input rotation uses it here -- finished bands are rotated by the threads that
+        // write them out (flush below), which frees nine registers of the step loop.
+        float o[9];
         {
             const float *fp = sd.frames + ((int64_t)gs + (own ? r : 0)) * 9;
 #pragma unroll
@@ -240,8 +253,83 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
                 for (int c = 0; c < 3; ++c) { yP[c] = 0.f; yQ[c] = 0.f; }
             }
         }
-        // (the event handler of the forward: closes and single-power slots first, then the band that opens)
-        auto emit = [&](int ps) {
+        // Forward output.  A finished band is one float per (row, channel) at stride F in OUT: written by the owners it is 64
+        // scattered lines per wave-store (measured: 0.22 of the launch's 0.53 ms at cfg2).  Instead the owners park the band
+        // in the stage buffer in ROW order (the staged x is dead after the prologue), and after the step's barrier every
+        // thread writes (row, channel) elements i, i + NT, ...: consecutive lanes 24 B apart, 12 lines per wave-store.
+        int pending = -1;                         // slot whose band waits in the stage (uniform)
+        int waiting = -1;                         // slot of a second band finished at the same step: in the owners' registers
+        float wP[3] = {0.f, 0.f, 0.f}, wQ[3] = {0.f, 0.f, 0.f};                 // until the stage is free (rare: last band + low-pass)
+        // The writers are the waves of the part's SHORT slices (upper half of the workgroup: rows are sorted by length), between
+        // their gathers and the step's barrier, where they would wait for the long slices anyway; a wave-store costs the CU
+        // 30-100 cycles of its one vector-memory path, which at the top of a step delayed everybody's gathers (measured).
+        // The vector track's band is parked in the local frames; the writer of element i = (row, channel c) forms row c of
+        // O_row x band (frame_to_global's arithmetic).
+        #ifndef ESCAT_BOTH_WRITERS
+#define ESCAT_BOTH_WRITERS 1              // 1: every wave writes; 2: the upper half of the waves
+#endif
+#ifndef ESCAT_BOTH_FLUSH_TOP
+#define ESCAT_BOTH_FLUSH_TOP 1            // 1: at the top of the step after the one that parked the band; 0: after that step's gathers
+#endif
+        constexpr int NTW = NT / ESCAT_BOTH_WRITERS, EPW = 3 * ESCAT_BOTH_WRITERS;      // writer threads; elements per writer and track
+        // Two bands at a time where the slots are adjacent: the writer keeps band f of its elements in registers until band
+        // f + 1 arrives and stores 8 B per element (half the store instructions and L2 write requests).
+        float keepS[EPW], keepV[EPW];
+        int kept = -1;                            // slot of the kept band (uniform)
+        auto put1 = [&](int slot) {
+            if (xr < NT - NTW) return;
+            int base = xr - (NT - NTW);
+            asm volatile("" : "+v"(base));
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) {
+                const int i = base + k * NTW;
+                if (i < rows * 3 && !(ESCAT_BOTH_EXP & 4)) {
+                    RESs[((int64_t)row0 * 3 + i) * F + slot] = keepS[k];
+                    RESv[((int64_t)row0 * 3 + i) * F + slot] = keepV[k];
+                }
+            }
+        };
+        auto flush = [&]() {
+            if ((ESCAT_BOTH_EXP & 16) || xr < NT - NTW) return;
+            int base = xr - (NT - NTW);
+            asm volatile("" : "+v"(base));        // (not loop-invariant for the optimiser: no addresses held across the steps)
+            const int n3 = rows * 3;
+            float vs[EPW], vv[EPW];
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) {
+                const int i = base + k * NTW, ii = i < n3 ? i : 0, row = ii / 3;
+                const float *f = sd.frames + (int64_t)gs * 9 + ii * 3;          // row c of the frame: o[3c], o[3c+1], o[3c+2]
+                const float x0 = inbV[row * 3], x1 = inbV[row * 3 + 1], x2 = inbV[row * 3 + 2];
+                vs[k] = inbS[ii];
+                vv[k] = fmaf(f[2], x2, fmaf(f[1], x1, f[0] * x0));               // frame_to_global
+            }
+            const bool pair = kept >= 0 && pending == kept + 1;
+            if (pair) {
+#pragma unroll
+                for (int k = 0; k < EPW; ++k) {
+                    const int i = base + k * NTW;
+                    if (i < n3 && !(ESCAT_BOTH_EXP & 4)) {
+                        *reinterpret_cast<f2u_k *>(RESs + ((int64_t)row0 * 3 + i) * F + kept) = f2u_k{keepS[k], vs[k]};
+                        *reinterpret_cast<f2u_k *>(RESv + ((int64_t)row0 * 3 + i) * F + kept) = f2u_k{keepV[k], vv[k]};
+                    }
+                }
+            } else {
+                if (kept >= 0) put1(kept);
+#pragma unroll
+                for (int k = 0; k < EPW; ++k) { keepS[k] = vs[k]; keepV[k] = vv[k]; }
+            }
+            kept = pair ? -1 : pending;
+        };
+        auto park = [&](int slot, const float (&a)[3], const float (&b)[3]) {   // a finished band, row order, into the stage
+            if (own) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { inbS[r * 3 + c] = a[c]; inbV[r * 3 + c] = b[c]; }
+            }
+            pending = slot;
+        };
+        // the event handler of the forward: closes and single-power slots first, then the band that opens.
+        // stage_read: the stage was read out after this step's opening barrier -- a slow wave may still be reading
+        auto emit = [&](int ps, bool stage_read) {
             const int nt = prog.s[ps].n;
             for (int k = 0; k < nt; ++k) {
                 const int kind = prog.s[ps].t[k].kind, slot = prog.s[ps].t[k].slot;
@@ -253,11 +341,21 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { a[c] += hP[c]; b[c] += hQ[c]; }
                 }
-                frame_to_global(b, o);
-                if (own) {
+                // (written with selects: as "if (pending >= 0) waiting = slot; else pending = slot;" the optimiser turns the two
+                // cursors into a two-element stack array -- scratch stores whose s_waitcnt vmcnt(0) then waits, every step, for the
+                // band stores issued at the step's top: measured +0.13 ms per launch)
+                const bool second = pending >= 0;     // a second band at one step: waits in registers
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { RESs[(orow + c) * F + slot] = a[c]; RESv[(orow + c) * F + slot] = b[c]; }
+                for (int c = 0; c < 3; ++c) { wP[c] = second ? a[c] : wP[c]; wQ[c] = second ? b[c] : wQ[c]; }
+                waiting = second ? slot : waiting;
+                if (!second) {
+                    if (stage_read) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (own) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { inbS[r * 3 + c] = a[c]; inbV[r * 3 + c] = b[c]; }
+                    }
                 }
+                pending = second ? pending : slot;
             }
             for (int k = 0; k < nt; ++k) {
                 const int kind = prog.s[ps].t[k].kind;
@@ -277,22 +375,15 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
                 float *z = smem + rows * 4 + xr;
                 z[0] = 0.f; z[VSTRIDE / 4] = 0.f; z[2 * VSTRIDE / 4] = 0.f; z[3 * VSTRIDE / 4] = 0.f;
             }
-            if (!BWD && prog.n > 0 && prog.s[0].step == 0) { emit(0); p = 1; }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // the next part: its slice words are here (the wait above covered them); forward: its x, now that inb is free
-        int swN = 0;
-        x_staged = false;
-        if (has_next) {
-            swN = metaS[wave * 8 + (lane & 7)];
-            if (!BWD) {
-                const int gsN = __builtin_amdgcn_readlane(swN, 3), rowsN = __builtin_amdgcn_readlane(swN, 4);
-                const int64_t r0N = sd.part_row0 ? sd.part_row0[liN] : gsN;
-                dma_in<NT>(inbS, INs + r0N * 3, rowsN * 3);
-                dma_in<NT>(inbV, INv + r0N * 3, rowsN * 3);
-                x_staged = true;
+            if (!BWD && prog.n > 0 && prog.s[0].step == 0) {
+                emit(0, true);                    // (x was read out of the stage just now: a band of step 0 waits for everybody)
+                p = 1;
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the next part: its slice words are here (the wait above covered them)
+        int swN = 0;
+        if (has_next) swN = metaS[wave * 8 + (lane & 7)];
         for (int t = 1; t <= T; ++t) {
             const int st = BWD ? T - t : t;
             float g[2][6];                        // backward: the upstream gradient of this step's (<= 2) events, asked for now
@@ -310,6 +401,18 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
                     }
                 }
             }
+            bool stage_read = false;              // forward: the band parked during the previous step leaves now
+            auto drain = [&]() {
+                if (pending >= 0) {
+                    flush(); pending = -1; stage_read = true;
+                    if (waiting >= 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        park(waiting, wP, wQ);
+                        waiting = -1; stage_read = false;
+                    }
+                }
+            };
+            if (!BWD && ESCAT_BOTH_FLUSH_TOP) drain();
             float aP[3] = {0.f, 0.f, 0.f}, aQ[3] = {0.f, 0.f, 0.f};
             op.gather(baseR, w, aP, aQ);
             if (has_tail && tn)
@@ -333,10 +436,11 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
                 }
             }
             if (!BWD) {
+                if (!ESCAT_BOTH_FLUSH_TOP) drain();
                 if (p < prog.n && prog.s[p].step == t) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { yP[c] = aP[c]; yQ[c] = aQ[c]; }
-                    emit(p); ++p;
+                    emit(p, stage_read); ++p;
                 }
             } else if (t == T && own) {           // the owner holds the answer of its row: straight to HBM
                 frame_to_global(aQ, o);
@@ -346,7 +450,21 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const unsigned tmp = baseR; baseR = baseW; baseW = tmp;
         }
+        if (!BWD) {                               // what is left after the last step
+            if (pending < 0 && kept >= 0) { put1(kept); kept = -1; }
+            while (pending >= 0) {
+                flush(); pending = -1;
+                if (waiting >= 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    park(waiting, wP, wQ);
+                    waiting = -1;
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                if (pending < 0 && kept >= 0) { put1(kept); kept = -1; }
+            }
+        }
         if (!has_next) break;
+        if (!BWD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the stage has been read: the next part's x may land
         li = liN; part = partN; sw = swN;
     }
 }
@@ -372,6 +490,8 @@ static int launch_both2(const int *colw, const float *mag, int n_parts, int max_
     if (dbg_per_cu > 0 && dbg_per_cu < per_cu) per_cu = dbg_per_cu;
     const int64_t resident = (int64_t)per_cu * escat_cu_count();
     const int grid = (int)(n_parts < resident ? n_parts : resident);
+    static const bool verbose = getenv("ESCAT_DBG_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "k_chain_both<%d,%d,%d>: lds %zu B, %d workgroups per CU, grid %d\n", DMAX, NT, (int)BWD, lds, cached_per_cu, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, colw, mag, sd, INs, INv, RESs, RESv, T, prog, F, n_parts, max_rows);
     return ESCAT_OK;
 }
