@@ -162,8 +162,8 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
     extern __shared__ __align__(16) float smem[];
     const unsigned lds0 = lds_addr(smem);
     const int stage = (max_rows * 3 + 3) & ~3;
-    float *inbS = smem + 4 * (VSTRIDE / 4), *inbV = inbS + stage;            // forward only
-    int *metaS = reinterpret_cast<int *>(smem + 4 * (VSTRIDE / 4) + (BWD ? 0 : 2 * stage));
+    float *inbS = smem + 4 * (VSTRIDE / 4), *inbV = inbS + stage;            // the stage: rows * 3 floats per track
+    int *metaS = reinterpret_cast<int *>(smem + 4 * (VSTRIDE / 4) + 2 * stage);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int xr = threadIdx.x;
     auto part_of = [&](int li_) { return sd.part_list ? sd.part_list[li_] : li_; };
@@ -217,27 +217,72 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         float hP[3] = {0.f, 0.f, 0.f}, hQ[3] = {0.f, 0.f, 0.f};               // forward: the open band of each track
         int p = 0;                                // cursor into prog.s (forward: next step to serve; backward: one past it)
         float yP[3], yQ[3];
+        // Backward input.  The upstream gradient of a step's events is one float per (row, channel) at stride F in G: read by
+        // the owners it is 64 scattered lines per wave-load, twelve of them per event step (measured: +10 us per step).  Instead
+        // every thread loads elements i, i + NT, ... (consecutive lanes 24 B apart; both slots of a step in one 8-byte load when
+        // they are adjacent) one step ahead, under that step's gathers, adds the step's terms and parks the sum in the stage in
+        // row order; the owners pick their row's six floats up from there.  (sum of the terms first, then onto the vector:
+        // fp32 rounding apart from adding the terms one by one, as the separate kernels do)
+        constexpr int EPL = 3;                    // elements per thread and track (rows * 3 <= 3 * NT)
+        float LA[EPL][2], LB[EPL][2];             // backward: the (<= 2) terms of the step being fetched, per element and track
+        auto gload = [&](int ps) {
+            const int nt = prog.s[ps].n, s0 = prog.s[ps].t[0].slot, s1 = nt > 1 ? prog.s[ps].t[1].slot : s0;
+            int base = xr;
+            asm volatile("" : "+v"(base));
+            const int n3 = rows * 3;
+            const bool adj = nt > 1 && (s1 == s0 + 1 || s0 == s1 + 1);
+            const int lo = s0 < s1 ? s0 : s1;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                const int i = base + k * NT, ii = i < n3 ? i : 0;
+                const float *gs_ = INs + ((int64_t)row0 * 3 + ii) * F, *gv_ = INv + ((int64_t)row0 * 3 + ii) * F;
+                if (adj) {
+                    const f2u_k a = *reinterpret_cast<const f2u_k *>(gs_ + lo), b = *reinterpret_cast<const f2u_k *>(gv_ + lo);
+                    LA[k][0] = s0 == lo ? a.x : a.y; LB[k][0] = s0 == lo ? a.y : a.x;
+                    LA[k][1] = s0 == lo ? b.x : b.y; LB[k][1] = s0 == lo ? b.y : b.x;
+                } else {
+                    LA[k][0] = gs_[s0]; LA[k][1] = gv_[s0];
+                    LB[k][0] = nt > 1 ? gs_[s1] : 0.f; LB[k][1] = nt > 1 ? gv_[s1] : 0.f;
+                }
+            }
+        };
+        auto gpark = [&](int ps) {
+            const int nt = prog.s[ps].n;
+            const bool n0 = prog.s[ps].t[0].kind & 4, n1 = nt > 1 && (prog.s[ps].t[1].kind & 4);
+            int base = xr;
+            asm volatile("" : "+v"(base));
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                const int i = base + k * NT;
+                float sP = n0 ? -LA[k][0] : LA[k][0], sQ = n0 ? -LA[k][1] : LA[k][1];
+                if (nt > 1) { sP += n1 ? -LB[k][0] : LB[k][0]; sQ += n1 ? -LB[k][1] : LB[k][1]; }
+                if (i < rows * 3) { inbS[i] = sP; inbV[i] = sQ; }
+            }
+        };
+        auto gtake = [&](float (&aP_)[3], float (&aQ_)[3]) {    // the owner adds its row's parked sums (vector track: into the local frame)
+            if (own) {
+                const float g0 = inbV[r * 3], g1 = inbV[r * 3 + 1], g2 = inbV[r * 3 + 2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) aP_[c] += inbS[r * 3 + c];
+                aQ_[0] += fmaf(o[6], g2, fmaf(o[3], g1, o[0] * g0));              // rotate_rows<true>
+                aQ_[1] += fmaf(o[7], g2, fmaf(o[4], g1, o[1] * g0));
+                aQ_[2] += fmaf(o[8], g2, fmaf(o[5], g1, o[2] * g0));
+            }
+        };
         if (BWD) {
             p = prog.n;
 #pragma unroll
             for (int c = 0; c < 3; ++c) { yP[c] = 0.f; yQ[c] = 0.f; }
-            if (p > 0 && prog.s[p - 1].step == T) {
-                --p;
-                const int nt = prog.s[p].n;
-                for (int k = 0; k < nt; ++k) {
-                    const int slot = prog.s[p].t[k].slot; const bool neg = prog.s[p].t[k].kind & 4;
-                    float g[3], gv[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { g[c] = own ? INs[(orow + c) * F + slot] : 0.f; gv[c] = own ? INv[(orow + c) * F + slot] : 0.f; }
-                    const float t0 = fmaf(o[6], gv[2], fmaf(o[3], gv[1], o[0] * gv[0]));       // rotate_rows<true>
-                    const float t1 = fmaf(o[7], gv[2], fmaf(o[4], gv[1], o[1] * gv[0]));
-                    const float t2 = fmaf(o[8], gv[2], fmaf(o[5], gv[1], o[2] * gv[0]));
-                    yP[0] += neg ? -g[0] : g[0]; yP[1] += neg ? -g[1] : g[1]; yP[2] += neg ? -g[2] : g[2];
-                    yQ[0] += neg ? -t0 : t0; yQ[1] += neg ? -t1 : t1; yQ[2] += neg ? -t2 : t2;
-                }
-            }
+            const bool evT = p > 0 && prog.s[p - 1].step == T;
+            if (evT) gload(p - 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                      // the previous part's last gathers are done: its vectors may be overwritten
+            __syncthreads();                      // the previous part's last gathers are done: its vectors and the stage are free
+            if (evT) {
+                gpark(p - 1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                gtake(yP, yQ);
+                --p;
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                      // every wave's x has landed
@@ -384,23 +429,18 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         // the next part: its slice words are here (the wait above covered them)
         int swN = 0;
         if (has_next) swN = metaS[wave * 8 + (lane & 7)];
+        if (BWD && p > 0 && prog.s[p - 1].step == T - 1) {    // events at step T - 1: no earlier step could fetch them (rare)
+            gload(p - 1);
+            gpark(p - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         for (int t = 1; t <= T; ++t) {
             const int st = BWD ? T - t : t;
-            float g[2][6];                        // backward: the upstream gradient of this step's (<= 2) events, asked for now
-            int gn = 0;
-            bool gneg[2] = {false, false};
-            if (BWD && p > 0 && prog.s[p - 1].step == st) {
-                --p;
-                gn = prog.s[p].n;
-                for (int k = 0; k < 2; ++k) {
-                    if (k < gn) {
-                        const int slot = prog.s[p].t[k].slot;
-                        gneg[k] = prog.s[p].t[k].kind & 4;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) { g[k][c] = own ? INs[(orow + c) * F + slot] : 0.f; g[k][3 + c] = own ? INv[(orow + c) * F + slot] : 0.f; }
-                    }
-                }
-            }
+            // backward: this step's events are in the stage already; the NEXT step's (if it has any) are fetched now
+            const bool ev_now = BWD && p > 0 && prog.s[p - 1].step == st;
+            const int pn = ev_now ? p - 2 : p - 1;
+            const bool ev_next = BWD && st > 0 && pn >= 0 && prog.s[pn].step == st - 1;
+            if (ev_next) gload(pn);
             bool stage_read = false;              // forward: the band parked during the previous step leaves now
             auto drain = [&]() {
                 if (pending >= 0) {
@@ -417,17 +457,7 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
             op.gather(baseR, w, aP, aQ);
             if (has_tail && tn)
                 both_tail<VSTRIDE>(mag, colw, te0, tn, smem + (baseR - lds0) / 4, aP, aQ, sd.pos_of_row);
-            if (BWD) {
-                for (int k = 0; k < 2; ++k) {
-                    if (k < gn) {
-                        const float t0 = fmaf(o[6], g[k][5], fmaf(o[3], g[k][4], o[0] * g[k][3]));
-                        const float t1 = fmaf(o[7], g[k][5], fmaf(o[4], g[k][4], o[1] * g[k][3]));
-                        const float t2 = fmaf(o[8], g[k][5], fmaf(o[5], g[k][4], o[2] * g[k][3]));
-                        aP[0] += gneg[k] ? -g[k][0] : g[k][0]; aP[1] += gneg[k] ? -g[k][1] : g[k][1]; aP[2] += gneg[k] ? -g[k][2] : g[k][2];
-                        aQ[0] += gneg[k] ? -t0 : t0; aQ[1] += gneg[k] ? -t1 : t1; aQ[2] += gneg[k] ? -t2 : t2;
-                    }
-                }
-            }
+            if (ev_now) { gtake(aP, aQ); --p; }
             {
                 const vf4 vp = {aP[0], aP[1], aP[2], 0.f}, vq = {aQ[0], aQ[1], aQ[2], 0.f};
                 if (own) {
@@ -442,10 +472,16 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
                     for (int c = 0; c < 3; ++c) { yP[c] = aP[c]; yQ[c] = aQ[c]; }
                     emit(p, stage_read); ++p;
                 }
-            } else if (t == T && own) {           // the owner holds the answer of its row: straight to HBM
-                frame_to_global(aQ, o);
+            } else {
+                if (ev_next) {                    // (consecutive event steps: the owners have to be done with the stage first)
+                    if (ev_now) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    gpark(pn);
+                }
+                if (t == T && own) {              // the owner holds the answer of its row: straight to HBM
+                    frame_to_global(aQ, o);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { RESs[orow + c] = aP[c]; RESv[orow + c] = aQ[c]; }
+                    for (int c = 0; c < 3; ++c) { RESs[orow + c] = aP[c]; RESv[orow + c] = aQ[c]; }
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const unsigned tmp = baseR; baseR = baseW; baseW = tmp;
@@ -473,7 +509,7 @@ template <int DMAX, int NT, bool BWD>
 static int launch_both2(const int *colw, const float *mag, int n_parts, int max_rows, const SellDev &sd, const float *INs,
                         const float *INv, float *RESs, float *RESv, int T, const BothProg &prog, int F, hipStream_t st)
 {
-    const size_t lds = (size_t)4 * 2 * (NT + 16) * 16 + (BWD ? 0 : 2 * (size_t)((max_rows * 3 + 3) & ~3) * 4) + (NT / 64) * 8 * sizeof(int);
+    const size_t lds = (size_t)4 * 2 * (NT + 16) * 16 + 2 * (size_t)((max_rows * 3 + 3) & ~3) * 4 + (NT / 64) * 8 * sizeof(int);
     if (lds > LDS_BUDGET) return fail(ESCAT_ERANGE, "both-tracks chain needs %zu B of LDS", lds);
     auto kern = k_chain_both<DMAX, NT, BWD>;
     int rc = set_lds(kern, lds); if (rc) return rc;
