@@ -13,15 +13,20 @@ batch of 4096 graphs x 500 nodes, symmetrised kNN k=10, scalar track x = pos
 batch: P-chain fwd, Q-chain fwd, then both backward w.r.t. x for a fixed upstream
 gradient (what autograd of the reference's get_Batch_Wjxs does).  Operators are
 canonical (int32 CSR / BSR-3) and resident in HBM before the timed region.
+Since round 3 the step goes through the both-tracks call (esc_gnn_amd.get_Batch_Wjxs_both:
+ESCGNNModular.forward's two _scatter calls, models/escgnn_modular.py:674, :685, as one call):
+when P pairs with the factored Q -- it does for builder-shaped operators like these -- the two
+chains of a direction are ONE launch (`route_step`, kernels_ms = both_fwd / both_bwd); otherwise,
+and in the "four_launches" variant, one chain per track and direction as before.
 
 Multi-GPU: graphs are independent diagonal blocks, so ranks take disjoint
 batches of the same size and no collective is on the data path ("weak" scaling);
 value = graphs all ranks processed / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the contract's fields plus
-  roofline      dominant kernel (Q-chain forward): algorithmic bytes per launch
-                (T(4(N+1)+40 nnz)+12N+12NF) / its mean HIP-event
-                duration inside the timed region, against 8 TB/s HBM peak.
+  roofline      dominant kernel (both-tracks forward; the Q-chain forward when the tracks do not pair): HBM bytes per
+                launch (measured, profiles/hbm_traffic.json) / its mean HIP-event duration inside the timed region,
+                against 8 TB/s HBM peak; SURVEY.md §8d's algorithmic figure beside it (see `regime`).
   cpu_baseline  the CPU oracle's torch.sparse.mm restatement of the reference
                 (kind "port"), timed on a bounded sample of the same batch.
   route_Q       which kernel family the drop-in chose by itself for THIS Q (round 3): the blocks of the synthetic batch are
@@ -309,6 +314,10 @@ def main():
             qf.signed.csr().sell(); qf.signed.csr_t().sell()
         else:
             q_.bsr3().sell(); q_.bsr3_t().sell()
+        from esc_gnn_amd import BothTracksOperator
+        bo = BothTracksOperator.pair(p_, q_)       # round 3: P and the factored Q as ONE operator (both tracks in one launch)
+        if bo is not None and bo.fits(plan_chain(scales_type="dyadic", J=args.J)):
+            bo.fop.signed.csr().sell(); bo.fop.signed.csr_t().sell()
         torch.cuda.synchronize()
         return p_, q_, (time.perf_counter() - tc0) * 1e3
     _, _, canon_first_ms = canonicalise()          # includes loading the library's code objects and torch's first calls
@@ -336,6 +345,7 @@ def main():
     evs = []
 
     def step(record, opQ_=None, evs=evs):
+        """the step as four launches: one chain per track and direction"""
         opQ_ = opQ if opQ_ is None else opQ_
         e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
         xs.grad = None; xv.grad = None
@@ -349,6 +359,26 @@ def main():
         Wv.backward(gv)
         if record: e[4].record()
         if record: evs.append(e)
+
+    # round 3: both tracks in one launch per direction (esc_gnn_amd/both.py) when P and Q pair -- what the drop-in's
+    # both-tracks call takes by itself for this batch
+    from esc_gnn_amd import get_Batch_Wjxs_both, BothTracksOperator
+    from esc_gnn_amd import both as _both
+    bop = BothTracksOperator.pair(opP, opQ) if os.environ.get("ESCAT_BOTH", "auto") != "0" else None
+    fused = bop is not None and bop.fits(plan) and _both._fusable(xs, xv, plan)
+    names2 = ("both_fwd", "both_bwd")
+
+    def step_both(record, evs=evs):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+        xs.grad = None; xv.grad = None
+        if record: e[0].record()
+        Ws, Wv = get_Batch_Wjxs_both(xs, opP, xv, opQ, scales_type="dyadic", J=args.J)
+        if record: e[1].record()
+        torch.autograd.backward([Ws, Wv], [gs, gv])
+        if record: e[2].record()
+        if record: evs.append(e)
+
+    main_step = step_both if fused else step
 
     def barrier():
         if world > 1:
@@ -369,11 +399,11 @@ def main():
                 "kernels_ms": perv, "note": note}
 
     for _ in range(args.warmup):
-        step(False)
+        main_step(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        main_step(True)
     barrier()
     dt = time.perf_counter() - t0
     from esc_gnn_amd.dist_utils import max_over_ranks
@@ -389,33 +419,53 @@ def main():
             raise SystemExit(3)
 
     if rank == 0:
-        per = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i, nm in enumerate(names)}
+        use = names2 if fused else names
+        per = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i, nm in enumerate(use)}
         bytes_q = alg_bytes_vector(N, nnz, T, F)
         bytes_p = alg_bytes_scalar(N, nnz, C, T, F)
-        alg_gbs = bytes_q / (per["Q_fwd"] * 1e-3) / 1e9
         comp_q = compulsory_bytes_vector(N, nnz, F)
         from esc_gnn_amd.operators import FactoredVectorOperator as _FVO
         from esc_gnn_amd.pyg_utilities import vector_route
         routed = vector_route(opQ, xv.detach(), F)
         factored_route = isinstance(routed, _FVO)
         half_route = (not factored_route) and opQ.bsr3().sell().half_val is not None
-        if factored_route:          # |p| + LDS row per nonzero, lane records, frames, x in, bank out
-            qkey, qname = "k_chain_sell<OpCsrV3", "k_chain_sell<OpCsrV3<..>, 512, false, false> (Q chain forward, factored form)"
-            comp_q = 6 * nnz + 12 * N + 36 * N + 12 * N + 12 * N * F
-        elif half_route:
-            qkey, qname = "k_chain_qh<", "k_chain_qh<.., 512, false, false> (Q chain forward, half-valued pack)"
-            comp_q = 20 * nnz + 12 * N + 12 * N + 12 * N * F
+        if fused:                   # both tracks: |p| + LDS row with sign bits per nonzero, lane records, frames (prologue +
+            # one re-read per written band pair), both x in, both banks out
+            qkey, qend = "k_chain_both<", ", false>"
+            qname = "k_chain_both<.., 512, false> (both tracks forward: P and the factored Q in one launch)"
+            comp_q = 6 * nnz + 12 * N + 36 * N + 24 * N + 24 * N * F
+            dom_ms = per["both_fwd"]
+            bytes_dom = bytes_q + bytes_p           # SURVEY 8d's figure for the two chains this launch replaces
+            lds_bytes = T * (2 * 16 * nnz + 4 * 16 * N)
         else:
-            qkey, qname = "k_chain_sell<OpBsr3", "k_chain_sell<OpBsr3<..>, 512, false, false> (Q chain forward)"
-        traffic = measured_traffic(args, qkey, ", false, false>")
+            qend = ", false, false>"
+            dom_ms = per["Q_fwd"]
+            bytes_dom = bytes_q
+            lds_bytes = T * (16 * nnz + 2 * 16 * N)
+            if factored_route:      # |p| + LDS row per nonzero, lane records, frames, x in, bank out
+                qkey, qname = "k_chain_sell<OpCsrV3", "k_chain_sell<OpCsrV3<..>, 512, false, false> (Q chain forward, factored form)"
+                comp_q = 6 * nnz + 12 * N + 36 * N + 12 * N + 12 * N * F
+            elif half_route:
+                qkey, qname = "k_chain_qh<", "k_chain_qh<.., 512, false, false> (Q chain forward, half-valued pack)"
+                comp_q = 20 * nnz + 12 * N + 12 * N + 12 * N * F
+            else:
+                qkey, qname = "k_chain_sell<OpBsr3", "k_chain_sell<OpBsr3<..>, 512, false, false> (Q chain forward)"
+        alg_gbs = bytes_dom / (dom_ms * 1e-3) / 1e9
+        traffic = measured_traffic(args, qkey, qend)
         hbm_bytes = traffic if traffic is not None else comp_q
-        achieved = hbm_bytes / (per["Q_fwd"] * 1e-3) / 1e9
-        # LDS side of the same kernel: every step gathers 16 B per stored block and stores each node's new vector twice
-        lds_bytes = T * (16 * nnz + 2 * 16 * N)
-        lds_gbs = lds_bytes / (per["Q_fwd"] * 1e-3) / 1e9
-        step_bytes = sum((measured_traffic(args, k, e) or 0) for k, e in
-                         ((qkey, ", false, false>"), (qkey, ", true, false>"),
-                          ("k_chain_sell<OpCsr<3", ", false, false>"), ("k_chain_sell<OpCsr<3", ", true, false>")))
+        achieved = hbm_bytes / (dom_ms * 1e-3) / 1e9
+        # LDS side of the same kernel: every step gathers 16 B per stored entry and track and stores each node's new vector twice
+        lds_gbs = lds_bytes / (dom_ms * 1e-3) / 1e9
+        if fused:
+            step_bytes = sum((measured_traffic(args, "k_chain_both<", e) or 0) for e in (", false>", ", true>"))
+        else:
+            step_bytes = sum((measured_traffic(args, k, e) or 0) for k, e in
+                             ((qkey, ", false, false>"), (qkey, ", true, false>"),
+                              ("k_chain_sell<OpCsr<3", ", false, false>"), ("k_chain_sell<OpCsr<3", ", true, false>")))
+        route_q = ("factored form recovered from the blocks at ingest (escat_recover_factored), relative reconstruction "
+                   f"error {opQ.factor_err:.2e}" if factored_route else
+                   "half-valued BSR-3 pack (every block value exact in fp16)" if half_route else
+                   "BSR-3 register kernel (fp32 pack)" + (f"; recovery refused, error {opQ.factor_err:.2e}" if opQ.factor_err is not None else ""))
         out = {
             "metric": "graphs/sec for P+Q scattering fwd+bwd (J=4)",
             "value": args.graphs * world * args.steps / dt,
@@ -429,24 +479,24 @@ def main():
                        "graphs_per_gpu": args.graphs, "nodes_per_graph": args.nodes, "k": args.k, "J": args.J,
                        "N": N, "nnz_P": nnz, "T": T, "F": F, "parallelism": f"dp{world} (graph shards, no data-path collective)"},
             "collective_backend": backend, "ranks_seen_by_allreduce": ranks_seen,
-            "route_Q": ("factored form recovered from the blocks at ingest (escat_recover_factored), relative reconstruction "
-                        f"error {opQ.factor_err:.2e}" if factored_route else
-                        "half-valued BSR-3 pack (every block value exact in fp16)" if half_route else
-                        "BSR-3 register kernel (fp32 pack)" + (f"; recovery refused, error {opQ.factor_err:.2e}" if opQ.factor_err is not None else "")),
+            "route_Q": route_q,
+            "route_step": ("both tracks in one launch per direction (escat_chain_both_f32 / _bwd_f32): P pairs with the factored Q "
+                           f"(|Pt| = P to {bop.mag_err:.1e} of max P); get_Batch_Wjxs_both takes it by itself" if fused else
+                           "one chain per track and direction (four launches)"),
             "roofline": {"bound": "hbm", "kernel": qname,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "bytes_basis": "measured (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/hbm_traffic.json, same libescat.so)"
                                         if traffic is not None else
                                         "compulsory bytes (operator read once + x in + bank out): no PMC summary for this build",
-                         "ms_per_launch": per["Q_fwd"],
+                         "ms_per_launch": dom_ms,
                          "compulsory_bytes_per_launch": comp_q,
                          "frac_of_measured_copy": achieved / copy_gbs,
-                         "algorithmic_bytes_per_launch": bytes_q, "algorithmic_GBs": alg_gbs,
+                         "algorithmic_bytes_per_launch": bytes_dom, "algorithmic_GBs": alg_gbs,
                          "whole_step_hbm_frac": (step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if step_bytes and traffic else None,
                          "lds": {"bytes": lds_bytes, "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                                  "frac": lds_gbs / LDS_PEAK_GBS,
-                                 "note": "T*(16 B gathered per block + two 16-B vector stores per node) vs ~150 TB/s aggregate "
+                                 "note": "T*(16 B gathered per stored entry and track + two 16-B vector stores per node and track) vs ~150 TB/s aggregate "
                                          "ds_read_b128 rate (MI355X_MICROARCH.md, LDS)"},
                          "regime": "the kernel keeps each graph's operator in registers for all T steps: HBM carries the "
                                    "operator once per chain (achieved/frac = those bytes / time vs the 8 TB/s peak); "
@@ -458,14 +508,19 @@ def main():
             "canonicalise_ms_once_per_batch": canon_ms,
             "canonicalise_ms_first_call_in_process": canon_first_ms,
             "kernels_ms": per,
-            "kernels_alg_GBs": {"P_fwd": bytes_p / (per["P_fwd"] * 1e-3) / 1e9, "Q_fwd": alg_gbs,
-                                "P_bwd": bytes_p / (per["P_bwd"] * 1e-3) / 1e9,
-                                "Q_bwd": bytes_q / (per["Q_bwd"] * 1e-3) / 1e9},
+            "kernels_alg_GBs": ({"both_fwd": alg_gbs, "both_bwd": (bytes_q + bytes_p) / (per["both_bwd"] * 1e-3) / 1e9} if fused else
+                                {"P_fwd": bytes_p / (per["P_fwd"] * 1e-3) / 1e9, "Q_fwd": alg_gbs,
+                                 "P_bwd": bytes_p / (per["P_bwd"] * 1e-3) / 1e9,
+                                 "Q_bwd": bytes_q / (per["Q_bwd"] * 1e-3) / 1e9}),
         }
         if world == 1:
             # secondary, NOT the headline: the same step with the routing of the vector operator forced (same inputs)
             from esc_gnn_amd import FactoredVectorOperator, operators as _ops
             out["variants"] = {}
+            if fused:
+                out["variants"]["four_launches"] = variant(opQ, "the same operators, one chain per track and direction (the routing of the "
+                                                                "vector operator as the drop-in picks it: " + route_q.split(" (")[0] + "): "
+                                                                "round 3's headline before the both-tracks launch")
             _ops.FACTOR_MODE = "0"
             opQb = ScatterOperator.from_bsr3(rowptr, col, blk_d, N)
             opQb.bsr3().sell(); opQb.bsr3_t().sell()

@@ -24,6 +24,9 @@ def test_bench_json_contract():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]
+    # the synthetic batch is builder-shaped: the two tracks pair and every direction is one launch, timed as such
+    assert d["route_step"].startswith("both tracks in one launch") and set(d["kernels_ms"]) == {"both_fwd", "both_bwd"}
+    assert "four_launches" in d["variants"] and set(d["variants"]["four_launches"]["kernels_ms"]) == {"P_fwd", "Q_fwd", "P_bwd", "Q_bwd"}
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
