@@ -33,7 +33,7 @@ int escat_fail(int code, const char *fmt, ...)      // shared with escat_build.h
     return code;
 }
 extern "C" const char *escat_last_error(void) { return g_err; }
-extern "C" int escat_abi_version(void) { return 4; }
+extern "C" int escat_abi_version(void) { return 5; }
 
 #ifdef ESCAT_STAMPS
 extern "C" int escat_debug_set_stamps_bsr3(void *), escat_debug_set_stamps_csr12(void *), escat_debug_set_stamps_csr34(void *),

@@ -134,6 +134,38 @@ def scatter(*, track, x0, P_or_Q, kwargs, ablate_second_order_wavelets=False, ca
     return W_tot.view(N, d, 1, -1).permute(0, 2, 1, 3)                                     # (N, 1, d, W)
 
 
+def scatter_both(*, x0_scalar, P, x0_vector, Q, kwargs, ablate_second_order_wavelets=False, cache: ScatteringCache = None):
+    """Both _scatter calls of ESCGNNModular.forward (models/escgnn_modular.py:674 scalar track on P, :685 vector track on Q)
+    as ONE call: returns (scatter(track='scalar', ...), scatter(track='vector', ...)) -- (N, C, W) and (N, 1, d, W).  When
+    the two operators pair (esc_gnn_amd.both: Q is P's factored companion, C = d = 3) the two first-order banks come from
+    one launch per direction; the orders 0/1/2 are then formed per track (escat_scatter_orders_f32).  Anything else runs
+    the two scatter calls as they are.  With a `cache` both results are stored under their tracks, so the model's own two
+    _scatter calls (escat_scatter) that follow hit the cache: call this once per batch ahead of the forward pass."""
+    from .both import bank_both
+    dkw = kwargs['diffusion_kwargs']
+    second = not ablate_second_order_wavelets
+    res = None
+    if x0_vector.dim() == 2 and not dkw.get('rescale_filtrations', False) and dkw.get('filter_stack_dim', -1) in (-1, 2):
+        N, d = x0_vector.shape
+        plan = plan_chain(scales_type=dkw.get('scales_type', 'dyadic'), diffusion_scales=dkw.get('diffusion_scales', None),
+                          J=dkw.get('J', 5), include_lowpass=dkw.get('include_lowpass', True))
+        flat = x0_vector.reshape(N * d, 1)
+        P_op, Q_op = as_operator(P), as_operator(Q)
+        if d == 3 and getattr(P_op, "n", -1) == x0_scalar.shape[0] and getattr(Q_op, "n", -1) == flat.shape[0]:
+            res = bank_both(x0_scalar, P_op, flat, Q_op, plan)
+        if res is not None:
+            Ws = _Orders.apply(x0_scalar, res[0], second)                                  # (N, C, W)
+            Wv = _Orders.apply(flat, res[1], second).view(N, d, 1, -1).permute(0, 2, 1, 3)  # (N, 1, d, W)
+            res = (Ws, Wv)
+    if res is None:
+        res = (scatter(track='scalar', x0=x0_scalar, P_or_Q=P, kwargs=kwargs, ablate_second_order_wavelets=ablate_second_order_wavelets),
+               scatter(track='vector', x0=x0_vector, P_or_Q=Q, kwargs=kwargs, ablate_second_order_wavelets=ablate_second_order_wavelets))
+    if cache is not None and not (torch.is_grad_enabled() and (x0_scalar.requires_grad or x0_vector.requires_grad)):
+        cache.store('scalar', x0_scalar, P, dkw, ablate_second_order_wavelets, res[0])
+        cache.store('vector', x0_vector, Q, dkw, ablate_second_order_wavelets, res[1])
+    return res
+
+
 def escat_scatter(self, *, track, x0, P_or_Q, kwargs):
     """method form: assign to ESCGNNModular._scatter (reads self.ablate_second_order_wavelets).  If the model carries
     an `escat_cache` attribute (a ScatteringCache) repeated calls on the same batch reuse the coefficients."""

@@ -279,7 +279,7 @@ int escat_sell_plan_slots(const int32_t *rowptr, const int32_t *col, const int32
 /* last error message of the calling thread ("" if none). */
 const char *escat_last_error(void);
 /* ABI version, bumped when a signature or a struct changes (4: escat_sell.ent_of_slot, escat_sell_dims.row_len_hist, the
- * single-pass ingest entry points). */
+ * single-pass ingest entry points; 5: escat_chain_both_f32 / _bwd_f32). */
 int escat_abi_version(void);
 
 /* Y = A X.  Replaces one torch.sparse.mm(P_sparse, Ptx) call

@@ -124,3 +124,35 @@ def test_both_tracks_c_abi_rejects_what_it_does_not_serve():
     lib = _lib.load()
     rc = lib.escat_chain_both_f32(0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0)
     assert rc != 0 and lib.escat_last_error()
+
+
+def test_scatter_both_equals_the_two_scatter_calls_and_primes_the_cache():
+    """scatter_both = ESCGNNModular.forward's two _scatter calls (orders 0/1/2 per track) on the fused first-order banks;
+    with a cache the model's own two calls that follow are hits"""
+    from esc_gnn_amd import scatter, scatter_both, ScatteringCache
+    B, n = 12, 200
+    pos, b = _built(B, n, 8, seed=21)
+    g = torch.Generator(device=DEV).manual_seed(8)
+    xs = torch.randn(B * n, 3, device=DEV, generator=g)
+    xv = torch.randn(B * n, 3, device=DEV, generator=g)
+    kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=3)}
+    cache = ScatteringCache()
+    Ws, Wv = scatter_both(x0_scalar=xs, P=b["P"], x0_vector=xv, Q=b["Q"], kwargs=kw, cache=cache)
+    Rs = scatter(track="scalar", x0=xs, P_or_Q=b["P"], kwargs=kw)
+    Rv = scatter(track="vector", x0=xv, P_or_Q=b["Q"], kwargs=kw)
+    assert Ws.shape == Rs.shape and Wv.shape == Rv.shape == (B * n, 1, 3, Ws.shape[-1])
+    assert float((Ws - Rs).abs().max()) <= 2e-6 * float(Rs.abs().max())
+    assert float((Wv - Rv).abs().max()) <= 2e-6 * float(Rv.abs().max())
+    assert scatter(track="scalar", x0=xs, P_or_Q=b["P"], kwargs=kw, cache=cache) is Ws and cache.hits == 1
+    assert scatter(track="vector", x0=xv, P_or_Q=b["Q"], kwargs=kw, cache=cache) is Wv and cache.hits == 2
+    # with gradients: one fused launch per direction, same gradients as the two calls
+    a1, v1 = xs.clone().requires_grad_(True), xv.clone().requires_grad_(True)
+    a2, v2 = xs.clone().requires_grad_(True), xv.clone().requires_grad_(True)
+    W1, V1 = scatter_both(x0_scalar=a1, P=b["P"], x0_vector=v1, Q=b["Q"], kwargs=kw)
+    W2 = scatter(track="scalar", x0=a2, P_or_Q=b["P"], kwargs=kw)
+    V2 = scatter(track="vector", x0=v2, P_or_Q=b["Q"], kwargs=kw)
+    Gs, Gv = torch.randn(W1.shape, device=DEV, generator=g), torch.randn(V1.shape, device=DEV, generator=g)
+    ((W1 * Gs).sum() + (V1 * Gv).sum()).backward()
+    ((W2 * Gs).sum() + (V2 * Gv).sum()).backward()
+    assert float((a1.grad - a2.grad).abs().max()) <= 1e-5 * float(a2.grad.abs().max())
+    assert float((v1.grad - v2.grad).abs().max()) <= 1e-5 * float(v2.grad.abs().max())

@@ -45,7 +45,7 @@ def _ops(sg, dev):
 def test_library_loaded_and_native():
     from esc_gnn_amd import _lib
     lib = _lib.load()
-    assert lib.escat_abi_version() == 4
+    assert lib.escat_abi_version() == 5
 
 
 @pytest.mark.parametrize("mode", list(MODES))

@@ -174,7 +174,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.escat_abi_version() == 4
+    assert lib.escat_abi_version() == 5
     assert lib.escat_chain_workspace_bytes(1000, 3) >= 2 * 1000 * 3 * 4
 
 
