@@ -809,6 +809,24 @@ def test_full_cfg2_batch_sampled_graphs_vs_c_oracle(oracle_lib, monkeypatch):
     check(opP, torch.randn(B * n, 3, device=dev, generator=gen), co.c_chain_csr, co.c_chain_csr_bwd, cp.col, cp.val, 1)
     xv = pos.reshape(-1, 1)
     check(opQ, xv, co.c_chain_bsr3, co.c_chain_bsr3_bwd, cq.col, cq.val, 3)
+    # both tracks in one launch per direction (the bench's headline step): the same 32 graphs, both banks and both gradients
+    from esc_gnn_amd import get_Batch_Wjxs_both, BothTracksOperator
+    assert BothTracksOperator.pair(opP, opQ) is not None
+    xs_b = torch.randn(B * n, 3, device=dev, generator=gen)
+    xs_g, xv_g = xs_b.clone().requires_grad_(True), xv.clone().requires_grad_(True)
+    Ws, Wv = get_Batch_Wjxs_both(xs_g, opP, xv_g, opQ, scales_type="dyadic", J=4)
+    Gs, Gv = torch.randn(Ws.shape, device=dev, generator=gen), torch.randn(Wv.shape, device=dev, generator=gen)
+    torch.autograd.backward([Ws, Wv], [Gs, Gv])
+    for g in sample:
+        g = int(g)
+        rp, cl, vl = blocks_of(g, cp.col, cp.val)
+        sl = slice(g * n, (g + 1) * n)
+        _close(Ws[sl], co.c_chain_csr(rp, cl, vl, xs_b[sl].cpu().numpy(), ev, plan.T, plan.F))
+        _close(xs_g.grad[sl], co.c_chain_csr_bwd(rp, cl, vl, Gs[sl].cpu().numpy(), ev, plan.T), rtol=1e-5)
+        rp, cl, vl = blocks_of(g, cq.col, cq.val)
+        sl = slice(g * n * 3, (g + 1) * n * 3)
+        _close(Wv[sl], co.c_chain_bsr3(rp, cl, vl, xv[sl].cpu().numpy().reshape(-1), ev, plan.T, plan.F))
+        _close(xv_g.grad[sl], co.c_chain_bsr3_bwd(rp, cl, vl, Gv[sl].cpu().numpy(), ev, plan.T), rtol=1e-5)
     from esc_gnn_amd.pyg_utilities import vector_route
     route_default = type(vector_route(opQ, xv, plan.F, plan.events)).__name__
     assert route_default == "FactoredVectorOperator"        # the builder's blocks: the factored form is recovered at ingest
