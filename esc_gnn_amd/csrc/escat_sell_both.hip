@@ -180,6 +180,12 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
     dma_meta(part);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int sw = metaS[wave * 8 + (lane & 7)];
+    // a part's lane record is requested while the part before it runs (first part: here): the frames' address depends on it
+    int rt, te0;
+    {
+        const int *lm0 = sd.lane_meta + ((int64_t)(part * sd.nsl + wave) * 64 + lane) * 3;
+        rt = lm0[0]; te0 = lm0[1];
+    }
     for (;;) {
         const int doff = __builtin_amdgcn_readlane(sw, 0), poff = __builtin_amdgcn_readlane(sw, 1);
         const int w = __builtin_amdgcn_readlane(sw, 2);
@@ -188,8 +194,6 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         const int liN = li + gridDim.x;
         const bool has_next = liN < n_parts;      // uniform
         const int partN = has_next ? part_of(liN) : 0;
-        const int *lm = sd.lane_meta + ((int64_t)(part * sd.nsl + wave) * 64 + lane) * 3;
-        const int rt = lm[0], te0 = lm[1];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // sw is in registers: its LDS words are free
         if (has_next) dma_meta(partN);
         if (!BWD) {                               // (the stage is free: the previous part's last band left behind a barrier)
@@ -427,8 +431,12 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // the next part: its slice words are here (the wait above covered them)
-        int swN = 0;
-        if (has_next) swN = metaS[wave * 8 + (lane & 7)];
+        int swN = 0, rtN = 0, te0N = 0;
+        if (has_next) {
+            swN = metaS[wave * 8 + (lane & 7)];
+            const int *lmN = sd.lane_meta + ((int64_t)(partN * sd.nsl + wave) * 64 + lane) * 3;
+            rtN = lmN[0]; te0N = lmN[1];          // (lands during the steps: two registers held, no dependent hop at the part's start)
+        }
         if (BWD && p > 0 && prog.s[p - 1].step == T - 1) {    // events at step T - 1: no earlier step could fetch them (rare)
             gload(p - 1);
             gpark(p - 1);
@@ -501,7 +509,7 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         }
         if (!has_next) break;
         if (!BWD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the stage has been read: the next part's x may land
-        li = liN; part = partN; sw = swN;
+        li = liN; part = partN; sw = swN; rt = rtN; te0 = te0N;
     }
 }
 
