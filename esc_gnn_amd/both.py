@@ -86,8 +86,9 @@ class BothTracksOperator:
         return BothTracksOperator(FactoredVectorOperator(fop.frames, signed), err)
 
 
-def _both_launch(bop: BothTracksOperator, plan, ins: torch.Tensor, inv: torch.Tensor, backward: bool):
-    """one call into the C ABI.  forward: ins, inv (n, 3) -> (n, 3, F) each; backward: (n, 3, F) each -> (n, 3) each."""
+def _both_launch(bop: BothTracksOperator, plan, ins: torch.Tensor, inv: torch.Tensor, backward: bool, view=None):
+    """one call into the C ABI.  forward: ins, inv (n, 3) -> (n, 3, F) each; backward: (n, 3, F) each -> (n, 3) each.
+    view: an OperatorBatch of the fused signed operator (parts of a stored operator, walked in place: escat_sell.part_list)."""
     lib = _lib.load()
     signed = bop.fop.signed
     form = signed.csr_t() if backward else signed.csr()
@@ -95,19 +96,25 @@ def _both_launch(bop: BothTracksOperator, plan, ins: torch.Tensor, inv: torch.Te
     sp = form.signed_pack()
     if sell is None or sp is None or sell.val_planes != 4:
         raise _lib.EscatError("escat: the both-tracks chain needs the sign-bit pack of the fused operator")
-    n, F = form.n, plan.F
+    n, F = (view.n if view is not None else form.n), plan.F
     dev = ins.device
     shape = (n, 3) if backward else (n, 3, F)
     outs = torch.empty(shape, dtype=torch.float32, device=dev)
     outv = torch.empty(shape, dtype=torch.float32, device=dev)
+    if n == 0:
+        return outs, outv
     ev = pu._events_array(plan.events)
     frames = bop.fop.frames
+    pl, pr, nl = 0, 0, 0
+    if view is not None:
+        plist, prow0 = view.lists_for(form)
+        pl, pr, nl = plist.data_ptr(), prow0.data_ptr(), int(plist.numel())
     sell_struct = _lib.EscatSell(sell.val.data_ptr(), sell.lc.data_ptr(), sell.lane_meta.data_ptr(), sell.dmax, sell.n_slices,
-                                 sell.slices_per_part, 4, 0, 0, 0, 0, 0, 0, 0, frames.data_ptr(), sell.layout,
+                                 sell.slices_per_part, 4, 0, 0, 0, pl, pr, nl, 0, frames.data_ptr(), sell.layout,
                                  sell.pos_of_row.data_ptr(), 0, 0, 0)
     fn = lib.escat_chain_both_bwd_f32 if backward else lib.escat_chain_both_f32
     with torch.cuda.device(dev):
-        rc = fn(pu._ptr(form.rowptr), pu._ptr(sp[0]), pu._ptr(sp[1]), n, form.nnz, pu._ptr(ins), pu._ptr(inv), plan.T,
+        rc = fn(pu._ptr(form.rowptr), pu._ptr(sp[0]), pu._ptr(sp[1]), form.n, form.nnz, pu._ptr(ins), pu._ptr(inv), plan.T,
                 ctypes.cast(ev, ctypes.c_void_p), len(plan.events), F, pu._ptr(outs), pu._ptr(outv),
                 pu._ptr(form.part_ptr), form.n_parts, form.max_part_rows, ctypes.cast(ctypes.pointer(sell_struct), ctypes.c_void_p),
                 pu._stream(dev))
@@ -117,23 +124,23 @@ def _both_launch(bop: BothTracksOperator, plan, ins: torch.Tensor, inv: torch.Te
 
 class _BothBank(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xs, xv, bop, plan):
-        ctx.bop, ctx.plan = bop, plan
-        return _both_launch(bop, plan, xs.contiguous(), xv.contiguous(), False)
+    def forward(ctx, xs, xv, bop, plan, view=None):
+        ctx.bop, ctx.plan, ctx.view = bop, plan, view
+        return _both_launch(bop, plan, xs.contiguous(), xv.contiguous(), False, view)
 
     @staticmethod
     def backward(ctx, gWs, gWv):
         ns, nv = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (ns or nv):
-            return None, None, None, None
+            return None, None, None, None, None
         gs = gWs.contiguous() if gWs is not None else None
         gv = gWv.contiguous() if gWv is not None else None
         if gs is None:
             gs = torch.zeros_like(gv)
         if gv is None:
             gv = torch.zeros_like(gs)
-        dxs, dxv = _both_launch(ctx.bop, ctx.plan, gs, gv, True)
-        return (dxs if ns else None), (dxv if nv else None), None, None
+        dxs, dxv = _both_launch(ctx.bop, ctx.plan, gs, gv, True, ctx.view)
+        return (dxs if ns else None), (dxv if nv else None), None, None, None
 
 
 def _fusable(x_s, x_v, plan) -> bool:
@@ -147,16 +154,37 @@ def bank_both(x_s, P_op, x_v, Q_op, plan):
     """(W_scalar (N, 3, F), W_vector (3N, 1, F)) from one launch, or None when the pair does not qualify."""
     if not _fusable(x_s, x_v, plan):
         return None
-    bop = BothTracksOperator.pair(P_op, Q_op)
-    if bop is None or bop.n != x_s.shape[0] or not bop.fits(plan):
-        return None
+    view = None
+    if isinstance(P_op, OperatorBatch):
+        # mini-batches drawn from a stored operator (ScatterOperator.select / FactoredVectorOperator.select): the stored P
+        # and Q pair once, the batch is the same list of parts of the fused operator
+        Qv = Q_op.signed if isinstance(Q_op, FactoredVectorOperator) else Q_op
+        if not isinstance(Qv, OperatorBatch) or not (P_op.part_ids is Qv.part_ids or bool(torch.equal(P_op.part_ids, Qv.part_ids))):
+            return None
+        Qb = Qv.base
+        if isinstance(Q_op, FactoredVectorOperator):
+            Qb = getattr(Qv.base, "_as_factored", None)
+            if Qb is None or Qb.frames is not Q_op.frames:
+                Qb = Qv.base._as_factored = FactoredVectorOperator(Q_op.frames, Qv.base)
+        bop = BothTracksOperator.pair(P_op.base, Qb)
+        if bop is None or not bop.fits(plan):
+            return None
+        view = getattr(P_op, "_both_view", None)
+        if view is None or view.base is not bop.fop.signed:
+            view = P_op._both_view = bop.fop.signed.select(P_op.part_ids)
+        if view.n != x_s.shape[0]:
+            return None
+    else:
+        bop = BothTracksOperator.pair(P_op, Q_op)
+        if bop is None or bop.n != x_s.shape[0] or not bop.fits(plan):
+            return None
     try:
-        Ws, Wv = _BothBank.apply(x_s, x_v.view(-1, 3), bop, plan)
+        Ws, Wv = _BothBank.apply(x_s, x_v.view(-1, 3), bop, plan, view)
     except _lib.EscatError as e:         # an event table the fused kernel does not serve (ESCAT_ERANGE)
         if "code -2" in str(e):
             return None
         raise
-    return Ws, Wv.view(x_v.shape[0], 1, -1)
+    return Ws, Wv.view(x_v.shape[0], 1, plan.F)
 
 
 def get_Batch_Wjxs_both(x_scalar: torch.Tensor, P_sparse, x_vector: torch.Tensor, Q_sparse, scales_type='dyadic',
@@ -172,7 +200,7 @@ def get_Batch_Wjxs_both(x_scalar: torch.Tensor, P_sparse, x_vector: torch.Tensor
         plan = plan_chain(scales_type=scales_type, diffusion_scales=diffusion_scales, J=J, include_lowpass=include_lowpass)
         if torch.is_tensor(x_scalar) and torch.is_tensor(x_vector) and x_scalar.dim() == 2 and x_vector.dim() == 2:
             P_op, Q_op = as_operator(P_sparse), as_operator(Q_sparse)
-            if isinstance(P_op, ScatterOperator) and P_op.n == x_scalar.shape[0] and getattr(Q_op, "n", -1) == x_vector.shape[0]:
+            if isinstance(P_op, (ScatterOperator, OperatorBatch)) and P_op.n == x_scalar.shape[0] and getattr(Q_op, "n", -1) == x_vector.shape[0]:
                 res = bank_both(x_scalar, P_op, x_vector, Q_op, plan)
                 if res is not None:
                     return res

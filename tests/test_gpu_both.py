@@ -156,3 +156,37 @@ def test_scatter_both_equals_the_two_scatter_calls_and_primes_the_cache():
     ((W2 * Gs).sum() + (V2 * Gv).sum()).backward()
     assert float((a1.grad - a2.grad).abs().max()) <= 1e-5 * float(a2.grad.abs().max())
     assert float((v1.grad - v2.grad).abs().max()) <= 1e-5 * float(v2.grad.abs().max())
+
+
+def test_both_tracks_on_views_of_a_stored_operator():
+    """mini-batches drawn from stored operators (select: parts in any order, repeats allowed): the stored P and Q pair once,
+    the fused launch walks the listed parts in place -- same banks and gradients as the two launches on the same views"""
+    from esc_gnn_amd import get_Batch_Wjxs, get_Batch_Wjxs_both
+    B, n = 40, 200
+    pos, b = _built(B, n, 8, seed=31)
+    P, Q, Qf = b["P"], b["Q"], b["Q_factored"]
+    n_parts = P.csr().n_parts
+    g = torch.Generator(device=DEV).manual_seed(9)
+    ids = torch.tensor([3, 0, n_parts - 1, 3, 7], device=DEV)
+    for Qsel in (Q, Qf):
+        vP, vQ = P.select(ids), Qsel.select(ids)
+        N = vP.n
+        xs = torch.randn(N, 3, device=DEV, generator=g)
+        xv = torch.randn(3 * N, 1, device=DEV, generator=g)
+        a1, v1 = xs.clone().requires_grad_(True), xv.clone().requires_grad_(True)
+        a2, v2 = xs.clone().requires_grad_(True), xv.clone().requires_grad_(True)
+        Ws, Wv = get_Batch_Wjxs_both(a1, vP, v1, vQ, J=3)
+        assert type(Ws.grad_fn).__name__ == "_BothBankBackward"          # the fused launch, not the fallback
+        Rs, Rv = get_Batch_Wjxs(a2, vP, J=3), get_Batch_Wjxs(v2, vQ, J=3)
+        assert Ws.shape == Rs.shape and Wv.shape == Rv.shape
+        tol = 0.0 if Qsel is Qf else 2e-6        # Q as blocks: the recovered magnitudes are replaced by P's values (<= 1e-6)
+        assert float((Ws - Rs).detach().abs().max()) == 0.0
+        assert float((Wv - Rv).detach().abs().max()) <= tol * float(Rv.detach().abs().max())
+        Gs, Gv = torch.randn(Ws.shape, device=DEV, generator=g), torch.randn(Wv.shape, device=DEV, generator=g)
+        torch.autograd.backward([Ws, Wv], [Gs, Gv])
+        torch.autograd.backward([Rs, Rv], [Gs, Gv])
+        assert float((a1.grad - a2.grad).abs().max()) <= 2e-6 * float(a2.grad.abs().max())
+        assert float((v1.grad - v2.grad).abs().max()) <= 2e-6 * float(v2.grad.abs().max())
+    e = torch.zeros(0, dtype=torch.long, device=DEV)
+    Ws, Wv = get_Batch_Wjxs_both(torch.zeros(0, 3, device=DEV), P.select(e), torch.zeros(0, 1, device=DEV), Qf.select(e), J=3)
+    assert Ws.shape[0] == 0 and Wv.shape[0] == 0
