@@ -9,7 +9,7 @@ args = ap.parse_args()
 from esc_gnn_amd import synthetic
 b = synthetic.ellipsoid_batch(args.graphs, args.nodes, args.k, seed=457893, workers=8)
 import torch
-from esc_gnn_amd import scatter, ScatterOperator
+from esc_gnn_amd import scatter, scatter_both, ScatterOperator
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(a).to(dev)
 opP = ScatterOperator.from_csr(t(b["rowptr"]), t(b["col"]), t(b["pval"]), b["N"])
@@ -32,4 +32,22 @@ for name, bwd in (("fwd", False), ("fwd+bwd", True)):
     for _ in range(args.reps): run(bwd)
     torch.cuda.synchronize(); res[name + "_ms"] = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
 res["graphs_per_s_fwd_bwd"] = round(args.graphs / (res["fwd+bwd_ms"] * 1e-3))
+# the same through the both-tracks call (first-order banks from one launch per direction, orders per track)
+def run2(bwd, grad):
+    a, v = (xs, xv) if grad else (xs.detach(), xv.detach())
+    Ws, Wv = scatter_both(x0_scalar=a, P=opP, x0_vector=v, Q=opQ, kwargs=kw)
+    if bwd:
+        xs.grad = None; xv.grad = None
+        torch.autograd.backward([Ws, Wv], [gs, gv])
+for name, bwd, grad in (("both_fwd_nograd", False, False), ("both_fwd+bwd", True, True)):
+    for _ in range(3): run2(bwd, grad)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.reps): run2(bwd, grad)
+    torch.cuda.synchronize(); res[name + "_ms"] = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
+def run3():
+    scatter(track="scalar", x0=xs.detach(), P_or_Q=opP, kwargs=kw); scatter(track="vector", x0=xv.detach(), P_or_Q=opQ, kwargs=kw)
+for _ in range(3): run3()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(args.reps): run3()
+torch.cuda.synchronize(); res["fwd_nograd_ms"] = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
 print(json.dumps(res))
