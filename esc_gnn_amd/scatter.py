@@ -13,6 +13,7 @@ can replace it on the model class:  ESCGNNModular._scatter = escat_scatter
 (and  model.escat_cache = ScatteringCache()  removes the redundant epoch-0 pass).
 """
 import ctypes
+import os
 import torch
 
 from . import _lib
@@ -54,12 +55,14 @@ class _Orders(torch.autograd.Function):
 
 
 def _scatter_rows(x, P_or_Q, dkw, second_order):
-    """(rows, C) -> (rows, C, W).  Without a gradient to x (how the reference trains: the scattering sits outside the
-    autograd graph, training/train.py:303-321) the register-resident chain writes the orders from its own epilogue, one
-    launch; with a gradient the bank is kept dense (bank + orders kernels): its backward then reads 6 floats per row
-    instead of 22, which outweighs the forward saving (measured: 2.02 vs 2.14 ms fwd+bwd at cfg2)."""
+    """(rows, C) -> (rows, C, W): the first-order bank (get_Batch_Wjxs), then the orders kernel.  ESCAT_ORDERS=epilogue
+    selects, for calls without a gradient to x (how the reference trains: the scattering sits outside the autograd graph,
+    training/train.py:303-321), the chain kernel that writes the orders from its own epilogue: one launch and no dense
+    bank held (6 floats per row less memory), but since the bank kernels moved to the row-ordered write-out it is the
+    slower of the two (cfg2, J=4: scalar 0.43 vs 0.34 ms, vector 0.51 vs 0.37 ms), so it is no longer the default."""
     want_grad = torch.is_grad_enabled() and x.requires_grad
-    if not want_grad and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] <= MAX_C and not dkw.get('rescale_filtrations', False) \
+    epilogue = os.environ.get("ESCAT_ORDERS", "kernel") == "epilogue"
+    if epilogue and not want_grad and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] <= MAX_C and not dkw.get('rescale_filtrations', False) \
             and dkw.get('filter_stack_dim', -1) in (-1, 2):
         try:
             plan = plan_chain(scales_type=dkw.get('scales_type', 'dyadic'), diffusion_scales=dkw.get('diffusion_scales', None),

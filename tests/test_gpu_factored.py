@@ -185,17 +185,21 @@ def test_store_with_frames_and_factored_views(tmp_path):
     G = torch.randn(Wq.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
     (Wq * G).sum().backward(); (Wf * G).sum().backward()
     assert float((xf.grad - x.grad).abs().max() / x.grad.abs().max()) <= 1e-5
-    # gradient-free _scatter on the views: one launch each (orders fused; with frames for the factored view)
+    # gradient-free _scatter on the views, orders from the chain's epilogue (ESCAT_ORDERS=epilogue; with frames for the factored view)
     from esc_gnn_amd import scatter
     from esc_gnn_amd.scatter import ScatteringCache
     kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=3, include_lowpass=True)}
     xn = pos[vq.row_index()[::3] // 3].contiguous()                  # (nodes of the view, 3)
     cache = ScatteringCache()
-    with torch.no_grad():
+    with torch.no_grad(), pytest.MonkeyPatch.context() as mp:
+        mp.setenv("ESCAT_ORDERS", "epilogue")
         Sq = scatter(track="vector", x0=xn, P_or_Q=vq, kwargs=kw)
         Sf = scatter(track="vector", x0=xn, P_or_Q=vf, kwargs=kw, cache=cache)
         assert scatter(track="vector", x0=xn, P_or_Q=vf, kwargs=kw, cache=cache) is Sf and cache.hits == 1
     assert Sf.shape == Sq.shape and _rel(Sf, Sq) <= 1e-5
+    with torch.no_grad():                                            # the default: bank + orders kernels
+        Dq, Df = scatter(track="vector", x0=xn, P_or_Q=vq, kwargs=kw), scatter(track="vector", x0=xn, P_or_Q=vf, kwargs=kw)
+    assert _rel(Dq, Sq) <= 1e-6 and _rel(Df, Sf) <= 1e-6
     with pytest.raises(KeyError):
         path2 = str(tmp_path / "plain.h5")
         write_dataset_hdf5(path2, pos, gp, 5, {"kernel": "gaussian", "gaussian_eps": 0.1}, chunk_graphs=4)

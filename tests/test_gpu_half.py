@@ -180,12 +180,14 @@ def test_half_pack_bitwise_on_synthetic_batches(oracle_lib, monkeypatch, B, n, k
     # T = 0 (P^0 only) and a long chain
     for kw2 in (dict(scales_type="custom", diffusion_scales=torch.tensor([0])), dict(scales_type="dyadic", J=5)):
         assert torch.equal(get_Batch_Wjxs(xv.to(dev), op_h, **kw2), get_Batch_Wjxs(xv.to(dev), op_f, **kw2))
-    # fused orders 0/1/2 (gradient-free _scatter: one launch)
+    # orders 0/1/2 from the chain's own epilogue (gradient-free _scatter with ESCAT_ORDERS=epilogue) and from the orders kernel
     pos = torch.from_numpy(b["pos"]).to(dev)
-    with torch.no_grad():
-        Sh = scatter(track="vector", x0=pos, P_or_Q=op_h, kwargs=dict(diffusion_kwargs=kw))
-        Sf = scatter(track="vector", x0=pos, P_or_Q=op_f, kwargs=dict(diffusion_kwargs=kw))
-    assert torch.equal(Sh, Sf)
+    for mode in ("epilogue", "kernel"):
+        with torch.no_grad(), pytest.MonkeyPatch.context() as mp:
+            mp.setenv("ESCAT_ORDERS", mode)
+            Sh = scatter(track="vector", x0=pos, P_or_Q=op_h, kwargs=dict(diffusion_kwargs=kw))
+            Sf = scatter(track="vector", x0=pos, P_or_Q=op_f, kwargs=dict(diffusion_kwargs=kw))
+        assert torch.equal(Sh, Sf)
     # a shuffled view of the stored operator (escat_sell.part_list)
     if op_h.bsr3().n_parts >= 4:
         ids = torch.randperm(op_h.bsr3().n_parts, generator=torch.Generator().manual_seed(4))[: max(2, B // 2)]

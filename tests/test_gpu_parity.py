@@ -564,12 +564,19 @@ def test_scatter_fused_and_two_kernel_forms_agree(monkeypatch):
                 key = (abl, str(kw["diffusion_kwargs"].get("scales_type")))
                 if path == "reg":
                     res[key] = (Ws.detach(), Wv.detach(), a.grad, v.grad)
-                    # without a gradient the same call is ONE fused launch (orders written by the chain's epilogue)
+                    # without a gradient and with ESCAT_ORDERS=epilogue the same call is ONE launch (orders written by the
+                    # chain's own epilogue)
+                    monkeypatch.setenv("ESCAT_ORDERS", "epilogue")
                     with torch.no_grad():
                         Fs = scatter(track="scalar", x0=xs, P_or_Q=opP, kwargs=kw, ablate_second_order_wavelets=abl)
                         Fv = scatter(track="vector", x0=xv, P_or_Q=opQ, kwargs=kw, ablate_second_order_wavelets=abl)
                     assert torch.equal(Fs[..., 0], xs) and Fs.shape == Ws.shape and Fv.shape == Wv.shape
                     assert (Fs - Ws).abs().max() <= 1e-6 * Ws.abs().max() and (Fv - Wv).abs().max() <= 1e-6 * Wv.abs().max()
+                    monkeypatch.delenv("ESCAT_ORDERS")
+                    with torch.no_grad():                       # the default: bank + orders kernels, bit-identical to the call above
+                        Ds = scatter(track="scalar", x0=xs, P_or_Q=opP, kwargs=kw, ablate_second_order_wavelets=abl)
+                        Dv = scatter(track="vector", x0=xv, P_or_Q=opQ, kwargs=kw, ablate_second_order_wavelets=abl)
+                    assert torch.equal(Ds, Ws.detach()) and torch.equal(Dv, Wv.detach())
                 else:
                     for got, want in zip((Ws.detach(), Wv.detach(), a.grad, v.grad), res[key]):
                         assert got.shape == want.shape

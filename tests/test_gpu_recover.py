@@ -103,9 +103,11 @@ def test_drop_in_takes_the_factored_kernel_by_itself_and_matches_the_reference(r
         _close(x.grad.reshape(-1, 1), r3g[f"f32_{name}_gx"].reshape(-1, 1))
     kw = {"diffusion_kwargs": dict(scales_type="dyadic", J=4, include_lowpass=True, diffusion_scales="dyadic")}
     ref = r3g["f32_scatter_vector"]
-    for grad in (False, True):                      # fused orders (one launch) and bank + orders kernels
+    for grad, mode in ((False, "epilogue"), (False, "kernel"), (True, "kernel")):   # orders from the chain's epilogue / the orders kernel
         x0 = xv.clone().requires_grad_(grad)
-        S = scatter(track="vector", x0=x0, P_or_Q=Q, kwargs=kw)
+        with pytest.MonkeyPatch.context() as mp:
+            mp.setenv("ESCAT_ORDERS", mode)
+            S = scatter(track="vector", x0=x0, P_or_Q=Q, kwargs=kw)
         assert S.shape == ref.shape
         _close(S.reshape(-1, S.shape[-1]), ref.reshape(-1, ref.shape[-1]), rtol=2e-5)   # products of two bands: 2 x 1e-5
 

@@ -392,7 +392,9 @@ def test_direct_chain_without_a_value_pack_equals_the_packed_chain(oracle_lib, m
             assert opq.bsr3_t().sell().direct == (mode == "auto")      # the transpose always finds a plan: Q's own, or P's
             with torch.no_grad():
                 Q2 = torch.sparse_coo_tensor(Qi, Qv, (3 * N, 3 * N), check_invariants=False)
+                monkeypatch.setenv("ESCAT_ORDERS", "epilogue")
                 S = scatter(track="vector", x0=xs, P_or_Q=Q2, kwargs=dict(diffusion_kwargs=kw))
+                monkeypatch.delenv("ESCAT_ORDERS")
             outs[mode] = (W.detach(), x.grad.clone(), S, G)
         assert torch.equal(outs["auto"][0], outs["0"][0]) and torch.equal(outs["auto"][1], outs["0"][1])
         assert torch.equal(outs["auto"][2], outs["0"][2])
