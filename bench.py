@@ -160,7 +160,40 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
         bb = build_PQ_batch(pos_d, gp, 16, {'kernel': 'epanechnikov', 'r_cut': 5.0})
         torch.cuda.synchronize(); build_s.append(time.perf_counter() - t0)
     same = bool(torch.equal(bb["rowptr"].cpu(), torch.from_numpy(c["rowptr"])) and torch.equal(bb["col"].cpu(), torch.from_numpy(c["col"])))
-    del bb
+    # The same chain on the operator as the product's builder hands it over: the builder knows the frames its blocks were made
+    # from (ScatterOperator.hint_frames), so Q = D Pt D^T is checked against every block instead of recovered, and the chain
+    # runs on the signed scalar operator (8 instead of 40 B per nonzero and step) between two rotation launches.
+    Qb = bb["Q"]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    fop = Qb.factored()
+    torch.cuda.synchronize(); check_s = time.perf_counter() - t0
+    fac = None
+    if fop is not None:
+        xb = pos_d.reshape(-1, 1).clone().requires_grad_(True)
+        g = torch.randn(3 * n, 1, F, device=dev)
+        ff = fb = 0.0
+        for r in range(reps + 1):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            xb.grad = None
+            e[0].record(); Wb = get_Batch_Wjxs(xb, Qb, scales_type="dyadic", J=J); e[1].record(); Wb.backward(g); e[2].record()
+            torch.cuda.synchronize()
+            if r >= 1:
+                ff += e[0].elapsed_time(e[1]) / reps; fb += e[1].elapsed_time(e[2]) / reps
+        # against the block chain on the SAME operator (the blocks without the hint: no factored form at this size)
+        Q0 = ScatterOperator.from_bsr3(bb["rowptr"], bb["col"], bb["blk"], n, parts=none)
+        with torch.no_grad():
+            W0 = get_Batch_Wjxs(xb.detach(), Q0, scales_type="dyadic", J=J)
+        fstep = 4 * (n + 1) + 8 * nnzb + 24 * n
+        fac = {"what": "Q of the product's builder (frames known -> factored form checked on every block, no recovery): rotation, "
+                       "3-channel chain on the signed scalar operator (k_csr_step, |value| + sign bits), rotation back",
+               "factor_check_s": check_s, "factor_err_rel": Qb.factor_err, "fwd_ms": ff, "bwd_ms": fb, "fwd_ms_per_step": ff / T,
+               "chains_per_s_fwd_bwd": 1e3 / (ff + fb), "speedup_vs_blocks": (tf + tb) / (ff + fb),
+               "max_rel_diff_vs_block_chain": float((Wb.detach() - W0).abs().max() / W0.abs().max()),
+               "bytes_per_step": fstep, "achieved_GBs": fstep / (ff / T * 1e-3) / 1e9,
+               "frac_of_hbm_peak": fstep / (ff / T * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "note": "the step is bound by the gather of x rows out of L2 (12 B per nonzero), not by the 8-B operator stream"}
+        del Wb, W0, Q0, g, xb
+    del bb, Qb, fop
     step_bytes = 4 * (n + 1) + 40 * nnzb + 24 * n
     return {"workload": f"cfg3: one ellipsoid cloud, {n} points, kNN k=16, Q (BSR-3) dyadic J={J} (T={T}, F={F}), fwd and bwd "
                         f"chains; multi-launch path (k_bsr3_step_staged), breadth-first relabelling at ingest",
@@ -173,7 +206,8 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
             "telescoping_max_abs_err": tele, "host_knn_s": c["gen_s"], "ingest_and_relabel_s": ingest_s,
             "gpu_build": {"what": "escat_build_knn_P_grid + frames + Q blocks + operator ingest of the same cloud (process_pyg_data's "
                                   "builder on the GPU)", "seconds": build_s[1], "seconds_first_call": build_s[0],
-                          "pattern_equal_to_host_kdtree": same}}
+                          "pattern_equal_to_host_kdtree": same},
+            "factored": fac}
 
 
 def bench_fresh_coo(b, dev, t, args, xs, xv, reps=5):

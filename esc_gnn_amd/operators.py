@@ -575,6 +575,7 @@ class ScatterOperator:
         self.row_inv = None             # old -> new (y = y'[row_inv])
         self._factored = None           # see factored(): FactoredVectorOperator, or False once recovery was refused
         self.factor_err = None          # relative reconstruction error of the recovery (diagnostic)
+        self._frames_hint = None        # hint_frames(): the frames the blocks were built from, when the builder knows them
         self.policy = None              # None: the module's INGEST_POLICY ("auto" = full); as_operator sets "single_use"
         self._fp16_probe = None         # values_look_fp16(), once
 
@@ -911,10 +912,61 @@ class ScatterOperator:
             self._fp16_probe = b.fp16_probe
         return self._fp16_probe
 
+    def hint_frames(self, frames: torch.Tensor, pval: Optional[torch.Tensor] = None):
+        """The local frames (nb, 3, 3) this BSR-3 operator's blocks were built from, in the row order the operator was
+        GIVEN in (process_pyg_data's builder knows them; the reference's files do not carry them).  factored() then
+        needs no recovery: it reads the signs off the blocks in the given frames and checks every block -- which also
+        serves operators the recovery kernel does not (one cloud larger than a workgroup's part: BASELINE cfg3).
+        pval: P's values in the operator's entry order (exact magnitudes, so that P pairs with the factored form)."""
+        if frames.dim() != 3 or frames.shape[1:] != (3, 3) or 3 * frames.shape[0] != self.n:
+            raise ValueError("escat: frames must be (rows / 3, 3, 3)")
+        self._frames_hint = (frames, pval)
+        self._factored = None
+
+    def _factored_from_hint(self):
+        """val3[e, c] = sign(O_i[:, c]^T Q_e O_j[:, c]) p_e and the largest entry of O_i^T Q_e O_j - diag(val3[e]) over
+        all blocks (fp64, in chunks); the signs are read off the blocks, not recomputed from the frames: a column pair
+        with <O_i[:, c], O_j[:, c]> ~ 0 would otherwise flip with the rounding of the dot product."""
+        b = self._bsr
+        frames, pval = self._frames_hint
+        dev = b.val.device
+        frames = frames.to(device=dev, dtype=torch.float32).contiguous()
+        permn = invn = None
+        fr = frames
+        if self.row_perm is not None:                   # the operator was relabelled (_reorder_if_large): follow it
+            permn, invn = self.row_perm[::3] // 3, self.row_inv[::3] // 3
+            fr, pval = frames[permn], None              # (entry order changed: magnitudes from the blocks)
+        rp = b.rowptr.long()
+        val3 = torch.empty((b.nnz, 3), dtype=torch.float32, device=dev)
+        err = torch.zeros((), dtype=torch.float64, device=dev)
+        fr64 = fr.double()
+        CH = 1 << 22
+        for e0 in range(0, b.nnz, CH):
+            e1 = min(b.nnz, e0 + CH)
+            rows = torch.searchsorted(rp, torch.arange(e0, e1, device=dev), right=True) - 1
+            M = fr64[rows].transpose(1, 2) @ b.val[e0:e1].double() @ fr64[b.col[e0:e1].long()]
+            d = torch.diagonal(M, dim1=1, dim2=2)
+            mag = pval[e0:e1].double()[:, None] if pval is not None else d.abs().mean(dim=1, keepdim=True)
+            v = torch.where(d >= 0, mag, -mag)
+            err = torch.maximum(err, (M - torch.diag_embed(v)).abs().amax())
+            val3[e0:e1] = v.float()
+        scale = float(b.val.abs().max()) if b.nnz else 0.0
+        self.factor_err = float(err) / scale if scale > 0 else float("inf")
+        if self.factor_err > FACTOR_TOL:
+            return None
+        signed = ScatterOperator(b.n, dev)
+        signed._csr = _Csr(b.rowptr, b.col, val3, b.n, (b.part_ptr, b.n_parts, b.max_part_rows))
+        signed.row_perm, signed.row_inv = permn, invn
+        signed.policy = self.policy
+        return FactoredVectorOperator(frames, signed)
+
     def factored(self):
         """Q = D Pt D^T recovered from the blocks (include/escat.h: escat_recover_factored): a FactoredVectorOperator that
         reproduces every block to FACTOR_TOL x max|Q|, or None (fp16-rounded blocks, 'procrustes' alignment, parts too
-        large, FACTOR_MODE "0").  Tried once per operator."""
+        large, FACTOR_MODE "0").  With hint_frames() the frames are given and only checked.  Tried once per operator."""
+        if self._factored is None and self._frames_hint is not None and self._bsr is not None and FACTOR_MODE != "0" \
+                and self._bsr.val.is_cuda and self._bsr.nnz > 0:
+            self._factored = self._factored_from_hint() or None         # (None: fall through to the recovery below)
         if self._factored is None:
             self._factored = False
             b = self._bsr

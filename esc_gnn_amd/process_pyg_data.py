@@ -216,6 +216,8 @@ def build_PQ_batch(pos: torch.Tensor, graph_ptr: torch.Tensor, k: int, local_pca
     out = {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk, "frames": frames, "nnz": nnz, "graph_ptr": graph_ptr,
            "P": ScatterOperator.from_csr(rowptr, col, pval, N, validate=False),
            "Q": ScatterOperator.from_bsr3(rowptr, col, blk, N, validate=False)}
+    if sing_vect_align_method == "column_dot" or not enforce_sign:
+        out["Q"].hint_frames(frames, pval)      # Q.factored() then needs no recovery (and serves clouds of any size)
     if factored:
         if sing_vect_align_method != "column_dot" and enforce_sign:
             raise ValueError("escat: only the column_dot alignment (or no sign enforcement) has the factored form")
@@ -357,8 +359,8 @@ def process_pyg_data(
     if graph_construction is not None:
         A_vals = edge_weight                # what the reference leaves in data.edge_weight (:758): the coalesced weights
     build = frames_and_Q if d == 3 else frames_and_Q_any_dim       # d = 3: the HIP kernels; any other d: batched torch on the GPU
-    _, blk = build(rowptr, col, pval, v, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
-                   sing_vect_align_method, tikhonov_eps if rank_deficiency_strategy is not None else None)
+    frames, blk = build(rowptr, col, pval, v, local_pca_kernel_fn_kwargs, use_mean_recentering, enforce_sign,
+                        sing_vect_align_method, tikhonov_eps if rank_deficiency_strategy is not None else None)
     batch = {"rowptr": rowptr, "col": col, "pval": pval, "blk": blk,
              "graph_ptr": torch.tensor([0, n], dtype=torch.int32)}
     parts = coo_parts(batch, 0, hdf5_tensor_dtype if not return_data_object else "float32")
@@ -375,6 +377,8 @@ def process_pyg_data(
         P._escat_operator = ScatterOperator.from_csr(rowptr, col, pval, n, validate=False)
         if d == 3:                                      # (any other d: get_Batch_Wjxs ingests the COO as a scalar operator)
             Q._escat_operator = ScatterOperator.from_bsr3(rowptr, col, blk, n, validate=False)
+            if sing_vect_align_method == "column_dot" or not enforce_sign:
+                Q._escat_operator.hint_frames(frames, pval)     # the frames the blocks were made from: no recovery needed
         out.P, out.Q = P, Q
         return out
     parts["original_idx"] = data_i

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .operators import ScatterOperator, OperatorBatch, FactoredVectorOperator, as_operator
+from .operators import ScatterOperator, OperatorBatch, FactoredVectorOperator, as_operator, SELL_MAX_PART_ROWS
 from .scales import ChainPlan, plan_chain
 
 LDS_BUDGET = 160 * 1024
@@ -226,8 +226,10 @@ def rotate_frames(frames: torch.Tensor, X: torch.Tensor, transpose: bool) -> tor
 
 
 def vector_route(op, x, F: int, events=()):
-    """the operator the vector track (x of shape (3N, 1) on a BSR-3 operator) really runs on: the factored form recovered
-    from the blocks when the operator has one and its graphs fit the register-resident path, else the operator itself.
+    """the operator the vector track (x of shape (3N, 1) on a BSR-3 operator) really runs on: the factored form (recovered
+    from the blocks, or checked against them in the builder's frames: ScatterOperator.hint_frames) when the operator has
+    one and its graphs fit the register-resident path or the operator takes the multi-launch path anyway, else the
+    operator itself.
     Not when a chain path is forced (ESCAT_CHAIN_PATH: a diagnostic of the BSR-3 kernels), and not for a |.| bank (the
     modulus must be taken in global coordinates; the factored kernel's slab is in the local frames)."""
     if os.environ.get("ESCAT_CHAIN_PATH", "") or any(ev[2] not in (1, -1) for ev in events):     # (+-1 + ESCAT_EVENT_ABS)
@@ -237,6 +239,10 @@ def vector_route(op, x, F: int, events=()):
     if isinstance(op, ScatterOperator) and op.has_bsr3:
         f = op.factored()
         if f is not None and f.fits_register_path(F):
+            return f
+        # a cloud too large for the register-resident path (BASELINE cfg3): both forms run one step kernel per power, and
+        # the factored one streams 8 instead of 40 B per nonzero (2 M points, J = 6: 8.4 instead of 20.8 ms per chain)
+        if f is not None and (op.row_perm is not None or op.bsr3().n_parts == 0 or op.bsr3().max_part_rows > SELL_MAX_PART_ROWS):
             return f
     elif isinstance(op, OperatorBatch) and op.base.has_bsr3:
         f = op.base.factored()

@@ -204,3 +204,65 @@ def test_store_with_frames_and_factored_views(tmp_path):
         path2 = str(tmp_path / "plain.h5")
         write_dataset_hdf5(path2, pos, gp, 5, {"kernel": "gaussian", "gaussian_eps": 0.1}, chunk_graphs=4)
         load_operator_store(path2, torch.device(DEV), factored=True)
+
+
+def test_builder_frames_hint_serves_clouds_of_any_size(monkeypatch):
+    """The builder knows the frames its blocks were made from (ScatterOperator.hint_frames): Q.factored() then reads the
+    signs off the blocks and checks every block instead of running the recovery -- which also covers a cloud larger
+    than a workgroup's part (BASELINE cfg3's shape: multi-launch path, with and without the locality relabelling), where
+    the recovery kernel does not apply.  The chain on such a Q takes the factored form by itself and stays within 1e-5
+    of the C oracle on the BLOCKS; frames that do not belong to the blocks are refused."""
+    from esc_gnn_amd import get_Batch_Wjxs, get_Batch_Wjxs_both, BothTracksOperator, ScatterOperator, FactoredVectorOperator, synthetic, plan_chain
+    from esc_gnn_amd.pyg_utilities import vector_route
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    from oracle import chain_oracle as co
+    kern = {"kernel": "gaussian", "gaussian_eps": 0.05}
+    plan = plan_chain(J=4)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    for n, reorder in ((3000, "auto"), (3000, "1")):
+        monkeypatch.setenv("ESCAT_REORDER", reorder)
+        pos = torch.from_numpy(synthetic.ellipsoid_clouds(1, n, seed=n).reshape(-1, 3)).to(DEV)
+        b = build_PQ_batch(pos, torch.tensor([0, n], dtype=torch.int32, device=DEV), 8, kern)
+        Q = b["Q"]
+        assert (Q.row_perm is not None) == (reorder == "1")
+        f = Q.factored()
+        assert isinstance(f, FactoredVectorOperator) and Q.factor_err <= 1e-6 and not f.fits_register_path(plan.F)
+        x = torch.randn(3 * n, 1, device=DEV, generator=g)
+        assert vector_route(Q, x, plan.F, plan.events) is f
+        xa = x.clone().requires_grad_(True)
+        W = get_Batch_Wjxs(xa, Q, J=4)
+        G = torch.randn(W.shape, device=DEV, generator=g)
+        W.backward(G)
+        rp, col, blk = b["rowptr"].cpu().numpy(), b["col"].cpu().numpy(), b["blk"].cpu().numpy()
+        ref = co.c_chain_bsr3(rp, col, blk, x.cpu().numpy().reshape(-1), ev, plan.T, plan.F)
+        refg = co.c_chain_bsr3_bwd(rp, col, blk, G.cpu().numpy(), ev, plan.T)
+        assert np.abs(W.detach().cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+        assert np.abs(xa.grad.cpu().numpy() - refg).max() <= 1e-5 * np.abs(refg).max()
+        # the same blocks without the hint: no factored form at this size (the recovery works per part of <= 512 rows)
+        Q0 = ScatterOperator.from_bsr3(b["rowptr"], b["col"], b["blk"], n, validate=False)
+        assert Q0.factored() is None and vector_route(Q0, x, plan.F, plan.events) is Q0
+        assert _rel(get_Batch_Wjxs(x, Q0, J=4), W) <= 1e-5
+        # frames that are not the blocks': refused, the chain stays on the blocks
+        O = torch.linalg.qr(torch.randn(n, 3, 3, device=DEV, generator=g))[0].contiguous()
+        Q0.hint_frames(O)
+        assert Q0.factored() is None and Q0.factor_err > 1e-3
+        with pytest.raises(ValueError):
+            Q0.hint_frames(O[:-1])
+    monkeypatch.delenv("ESCAT_REORDER")
+    # a batch of small graphs: the hinted form is what the recovery would find, P pairs with it, both tracks in one launch
+    pos, b = _built(64, 128, 5, seed=11, factored=False)
+    f = b["Q"].factored()
+    assert f is not None and b["Q"].factor_err <= 1e-6 and f.fits_register_path(plan.F)
+    assert torch.equal(f.signed.csr().val.abs(), b["pval"][:, None].expand(-1, 3))          # P's own magnitudes
+    assert BothTracksOperator.pair(b["P"], b["Q"]) is not None
+    xs, xv = torch.randn(64 * 128, 3, device=DEV, generator=g), torch.randn(3 * 64 * 128, 1, device=DEV, generator=g)
+    Ws, Wv = get_Batch_Wjxs_both(xs, b["P"], xv, b["Q"], J=4)
+    rp, col = b["rowptr"].cpu().numpy(), b["col"].cpu().numpy()
+    refs = co.c_chain_csr(rp, col, b["pval"].cpu().numpy(), xs.cpu().numpy(), ev, plan.T, plan.F)
+    refv = co.c_chain_bsr3(rp, col, b["blk"].cpu().numpy(), xv.cpu().numpy().reshape(-1), ev, plan.T, plan.F)
+    assert np.abs(Ws.cpu().numpy() - refs).max() <= 1e-5 * np.abs(refs).max()
+    assert np.abs(Wv.cpu().numpy().reshape(refv.shape) - refv).max() <= 1e-5 * np.abs(refv).max()
+    # 'procrustes' blocks carry no hint (and have no factored form)
+    bp = build_PQ_batch(pos[:128], torch.tensor([0, 128], dtype=torch.int32, device=DEV), 5, kern, sing_vect_align_method="procrustes")
+    assert bp["Q"]._frames_hint is None
