@@ -124,10 +124,15 @@ def cpu_baseline(b, n_graphs, n_per_graph, J, threads):
 
 
 def bench_cfg3(c, dev, t, args, J=6, reps=3):
-    """secondary, N = 1 only: BASELINE configs[2] -- one cloud (default 2 M points, k = 16), vector track Q (BSR-3),
-    dyadic J = 6 (T = 64).  The graph does not fit LDS: one step kernel per power (k_bsr3_step_staged), the operator streamed
-    from HBM every step, rows relabelled breadth-first once at ingest.  HIP-event times of the whole chain, forward and
-    backward; the step kernel's roofline uses SURVEY 8d's per-step bytes 4(N+1) + 40 nnz + 24 N."""
+    """secondary, N = 1 only: BASELINE configs[2] -- one cloud (default 2 M points, k = 16), vector track Q given as its
+    BSR-3 blocks, dyadic J = 6 (T = 64).  The graph does not fit LDS: one step kernel per power, the operator streamed from
+    HBM every step, rows relabelled breadth-first once at ingest.  Two chains on the same operator, HIP-event times forward
+    and backward:
+      * on the blocks (k_bsr3_step_staged; ESCAT_CHAIN_PATH=multi pins the route): the top-level keys and `roofline`
+        (SURVEY 8d's per-step bytes 4(N+1) + 40 nnz + 24 N) -- comparable with rounds 1-2;
+      * `factored`: what the drop-in takes by itself since round 3 -- the frames recovered from the blocks across the
+        whole device (esc_gnn_amd/recover_large.py, timed), every block checked, then rotation + the 3-channel chain on the
+        signed scalar operator (8 B per nonzero and step) + rotation back."""
     import torch
     from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, plan_chain
     none = (torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
@@ -139,19 +144,50 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
     n, nnzb, T, F = c["N"], c["nnz"], plan.T, plan.F
     xv = t(c["pos"]).reshape(-1, 1).clone().requires_grad_(True)
     g = torch.randn(3 * n, 1, F, device=dev)
-    tf = tb = 0.0
-    for r in range(reps + 1):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        xv.grad = None
-        e[0].record(); W = get_Batch_Wjxs(xv, op, scales_type="dyadic", J=J); e[1].record(); W.backward(g); e[2].record()
-        torch.cuda.synchronize()
-        if r >= 1:
-            tf += e[0].elapsed_time(e[1]) / reps; tb += e[1].elapsed_time(e[2]) / reps
-    tele = float((W.detach().sum(-1).reshape(-1) - xv.detach().reshape(-1)).abs().max())
-    # the same cloud's operators built by the product's own builder (grid kNN + P + local-PCA frames + Q blocks, all on
-    # the GPU), timed, its pattern checked against the host kd-tree's that fed the chain above
-    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+
+    def chain_times():
+        tf = tb = 0.0
+        for r in range(reps + 1):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            xv.grad = None
+            e[0].record(); W = get_Batch_Wjxs(xv, op, scales_type="dyadic", J=J); e[1].record(); W.backward(g); e[2].record()
+            torch.cuda.synchronize()
+            if r >= 1:
+                tf += e[0].elapsed_time(e[1]) / reps; tb += e[1].elapsed_time(e[2]) / reps
+        return tf, tb, W.detach()
+    prev = os.environ.get("ESCAT_CHAIN_PATH")
+    os.environ["ESCAT_CHAIN_PATH"] = "multi"          # the blocks themselves (the route a forced chain path keeps)
+    try:
+        tf, tb, W = chain_times()
+    finally:
+        if prev is None:
+            del os.environ["ESCAT_CHAIN_PATH"]
+        else:
+            os.environ["ESCAT_CHAIN_PATH"] = prev
+    tele = float((W.sum(-1).reshape(-1) - xv.detach().reshape(-1)).abs().max())
+    # the default route: frames from the blocks alone, once per operator
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    fop = op.factored()
+    torch.cuda.synchronize(); recover_s = time.perf_counter() - t0
+    fac = {"route": "blocks (no factored form found)", "recover_s": recover_s, "factor_err_rel": op.factor_err}
+    if fop is not None:
+        ff, fb, Wf = chain_times()
+        fstep = 4 * (n + 1) + 8 * nnzb + 24 * n
+        fac = {"route": "factored form recovered from the blocks alone (recover_large: tree by pointer doubling, gauge from the "
+                        "holonomies, level walk; every block checked) -> rotation, 3-channel chain on the signed scalar operator "
+                        "(k_csr_step, |value| + sign bits), rotation back",
+               "recover_s": recover_s, "factor_err_rel": op.factor_err, "fwd_ms": ff, "bwd_ms": fb, "fwd_ms_per_step": ff / T,
+               "chains_per_s_fwd_bwd": 1e3 / (ff + fb), "speedup_vs_blocks": (tf + tb) / (ff + fb),
+               "max_rel_diff_vs_block_chain": float((Wf - W).abs().max() / W.abs().max()),
+               "bytes_per_step": fstep, "achieved_GBs": fstep / (ff / T * 1e-3) / 1e9,
+               "frac_of_hbm_peak": fstep / (ff / T * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "note": "the step is bound by the gather of x rows out of L2 (12 B per nonzero), not by the 8-B operator stream"}
+        del Wf
     del W, g
+    # the same cloud's operators built by the product's own builder (grid kNN + P + local-PCA frames + Q blocks, all on
+    # the GPU), timed, its pattern checked against the host kd-tree's that fed the chains above.  The builder knows the
+    # frames its blocks were made from (ScatterOperator.hint_frames): its Q needs the check of every block only.
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
     gp = torch.tensor([0, n], dtype=torch.int32)
     pos_d = t(c["pos"])
     build_s = []
@@ -160,40 +196,11 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
         bb = build_PQ_batch(pos_d, gp, 16, {'kernel': 'epanechnikov', 'r_cut': 5.0})
         torch.cuda.synchronize(); build_s.append(time.perf_counter() - t0)
     same = bool(torch.equal(bb["rowptr"].cpu(), torch.from_numpy(c["rowptr"])) and torch.equal(bb["col"].cpu(), torch.from_numpy(c["col"])))
-    # The same chain on the operator as the product's builder hands it over: the builder knows the frames its blocks were made
-    # from (ScatterOperator.hint_frames), so Q = D Pt D^T is checked against every block instead of recovered, and the chain
-    # runs on the signed scalar operator (8 instead of 40 B per nonzero and step) between two rotation launches.
-    Qb = bb["Q"]
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    fop = Qb.factored()
+    hinted = bb["Q"].factored() is not None
     torch.cuda.synchronize(); check_s = time.perf_counter() - t0
-    fac = None
-    if fop is not None:
-        xb = pos_d.reshape(-1, 1).clone().requires_grad_(True)
-        g = torch.randn(3 * n, 1, F, device=dev)
-        ff = fb = 0.0
-        for r in range(reps + 1):
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            xb.grad = None
-            e[0].record(); Wb = get_Batch_Wjxs(xb, Qb, scales_type="dyadic", J=J); e[1].record(); Wb.backward(g); e[2].record()
-            torch.cuda.synchronize()
-            if r >= 1:
-                ff += e[0].elapsed_time(e[1]) / reps; fb += e[1].elapsed_time(e[2]) / reps
-        # against the block chain on the SAME operator (the blocks without the hint: no factored form at this size)
-        Q0 = ScatterOperator.from_bsr3(bb["rowptr"], bb["col"], bb["blk"], n, parts=none)
-        with torch.no_grad():
-            W0 = get_Batch_Wjxs(xb.detach(), Q0, scales_type="dyadic", J=J)
-        fstep = 4 * (n + 1) + 8 * nnzb + 24 * n
-        fac = {"what": "Q of the product's builder (frames known -> factored form checked on every block, no recovery): rotation, "
-                       "3-channel chain on the signed scalar operator (k_csr_step, |value| + sign bits), rotation back",
-               "factor_check_s": check_s, "factor_err_rel": Qb.factor_err, "fwd_ms": ff, "bwd_ms": fb, "fwd_ms_per_step": ff / T,
-               "chains_per_s_fwd_bwd": 1e3 / (ff + fb), "speedup_vs_blocks": (tf + tb) / (ff + fb),
-               "max_rel_diff_vs_block_chain": float((Wb.detach() - W0).abs().max() / W0.abs().max()),
-               "bytes_per_step": fstep, "achieved_GBs": fstep / (ff / T * 1e-3) / 1e9,
-               "frac_of_hbm_peak": fstep / (ff / T * 1e-3) / 1e9 / HBM_PEAK_GBS,
-               "note": "the step is bound by the gather of x rows out of L2 (12 B per nonzero), not by the 8-B operator stream"}
-        del Wb, W0, Q0, g, xb
-    del bb, Qb, fop
+    hint = {"factored_form_from_the_builders_frames": hinted, "check_s": check_s, "factor_err_rel": bb["Q"].factor_err}
+    del bb
     step_bytes = 4 * (n + 1) + 40 * nnzb + 24 * n
     return {"workload": f"cfg3: one ellipsoid cloud, {n} points, kNN k=16, Q (BSR-3) dyadic J={J} (T={T}, F={F}), fwd and bwd "
                         f"chains; multi-launch path (k_bsr3_step_staged), breadth-first relabelling at ingest",
@@ -206,7 +213,7 @@ def bench_cfg3(c, dev, t, args, J=6, reps=3):
             "telescoping_max_abs_err": tele, "host_knn_s": c["gen_s"], "ingest_and_relabel_s": ingest_s,
             "gpu_build": {"what": "escat_build_knn_P_grid + frames + Q blocks + operator ingest of the same cloud (process_pyg_data's "
                                   "builder on the GPU)", "seconds": build_s[1], "seconds_first_call": build_s[0],
-                          "pattern_equal_to_host_kdtree": same},
+                          "pattern_equal_to_host_kdtree": same, "frames_hint": hint},
             "factored": fac}
 
 

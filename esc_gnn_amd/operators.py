@@ -247,6 +247,9 @@ FACTOR_MODE = os.environ.get("ESCAT_Q_FACTOR", "auto")
 # "direct" BSR-3 chains (no value pack, include/escat.h: escat_sell.ent_of_slot) for single-use operators; "0": never
 DIRECT_MODE = os.environ.get("ESCAT_Q_DIRECT", "auto")
 FACTOR_TOL = 1e-6
+# one large connected cloud (relabelled breadth-first at ingest, BASELINE cfg3): recover the frames across the whole device
+# (esc_gnn_amd/recover_large.py; ~3.5 s once for 2 M nodes, the chain then runs 2.5x faster).  "0": such operators stay BSR-3.
+LARGE_RECOVERY = os.environ.get("ESCAT_Q_FACTOR_LARGE", "auto") != "0"
 
 # How much to invest in an operator at ingest.
 #   "full": everything that makes the chains fast -- the matching slot plan of the SELL pack, the factored form of Q -- a
@@ -924,18 +927,23 @@ class ScatterOperator:
         self._factored = None
 
     def _factored_from_hint(self):
-        """val3[e, c] = sign(O_i[:, c]^T Q_e O_j[:, c]) p_e and the largest entry of O_i^T Q_e O_j - diag(val3[e]) over
+        """the factored form in the frames of hint_frames(), or None if they do not reproduce the blocks"""
+        frames, pval = self._frames_hint
+        frames = frames.to(device=self._bsr.val.device, dtype=torch.float32).contiguous()
+        if self.row_perm is not None:                   # the operator was relabelled (_reorder_if_large): follow it
+            return self._factored_in_frames(frames[self.row_perm[::3] // 3], None, frames)   # (entry order changed: magnitudes from the blocks)
+        return self._factored_in_frames(frames, pval, frames)
+
+    def _factored_in_frames(self, fr, pval, frames_given):
+        """fr: frames in the row order of the stored blocks, frames_given: the same in the order the operator was given in.
+        val3[e, c] = sign(O_i[:, c]^T Q_e O_j[:, c]) p_e and the largest entry of O_i^T Q_e O_j - diag(val3[e]) over
         all blocks (fp64, in chunks); the signs are read off the blocks, not recomputed from the frames: a column pair
         with <O_i[:, c], O_j[:, c]> ~ 0 would otherwise flip with the rounding of the dot product."""
         b = self._bsr
-        frames, pval = self._frames_hint
         dev = b.val.device
-        frames = frames.to(device=dev, dtype=torch.float32).contiguous()
         permn = invn = None
-        fr = frames
-        if self.row_perm is not None:                   # the operator was relabelled (_reorder_if_large): follow it
+        if self.row_perm is not None:
             permn, invn = self.row_perm[::3] // 3, self.row_inv[::3] // 3
-            fr, pval = frames[permn], None              # (entry order changed: magnitudes from the blocks)
         rp = b.rowptr.long()
         val3 = torch.empty((b.nnz, 3), dtype=torch.float32, device=dev)
         err = torch.zeros((), dtype=torch.float64, device=dev)
@@ -952,13 +960,26 @@ class ScatterOperator:
             val3[e0:e1] = v.float()
         scale = float(b.val.abs().max()) if b.nnz else 0.0
         self.factor_err = float(err) / scale if scale > 0 else float("inf")
-        if self.factor_err > FACTOR_TOL:
+        if not self.factor_err <= FACTOR_TOL:
             return None
         signed = ScatterOperator(b.n, dev)
         signed._csr = _Csr(b.rowptr, b.col, val3, b.n, (b.part_ptr, b.n_parts, b.max_part_rows))
         signed.row_perm, signed.row_inv = permn, invn
         signed.policy = self.policy
-        return FactoredVectorOperator(frames, signed)
+        return FactoredVectorOperator(frames_given, signed)
+
+    def _factored_large(self):
+        """one large connected cloud (relabelled breadth-first at ingest): frames from the blocks alone across the whole
+        device (esc_gnn_amd.recover_large), then the same check of every block as for hinted frames"""
+        from .recover_large import recover_frames_large, workspace_bytes
+        b = self._bsr
+        free = torch.cuda.mem_get_info(b.val.device)[0]
+        if workspace_bytes(b.nnz, b.n) > free // 2:
+            return None
+        G = recover_frames_large(b.rowptr, b.col, b.val)
+        if G is None:
+            return None
+        return self._factored_in_frames(G, None, G[self.row_inv[::3] // 3].contiguous())
 
     def factored(self):
         """Q = D Pt D^T recovered from the blocks (include/escat.h: escat_recover_factored): a FactoredVectorOperator that
@@ -967,6 +988,10 @@ class ScatterOperator:
         if self._factored is None and self._frames_hint is not None and self._bsr is not None and FACTOR_MODE != "0" \
                 and self._bsr.val.is_cuda and self._bsr.nnz > 0:
             self._factored = self._factored_from_hint() or None         # (None: fall through to the recovery below)
+        if self._factored is None and self.row_perm is not None and self._bsr is not None and FACTOR_MODE != "0" and LARGE_RECOVERY \
+                and _policy_of(self._stamp(self._bsr)) != "single_use" and self._bsr.val.is_cuda and self._bsr.nnz > 0 \
+                and not self.values_look_fp16():
+            self._factored = self._factored_large() or False
         if self._factored is None:
             self._factored = False
             b = self._bsr

@@ -35,9 +35,12 @@ def test_bench_json_contract():
     c3 = d["cfg3"]
     assert c3["nodes"] == 30000 and c3["fwd_ms"] > 0 and c3["roofline"]["bound"] == "hbm" and c3["telescoping_max_abs_err"] < 1e-4
     assert c3["gpu_build"]["pattern_equal_to_host_kdtree"] is True and c3["gpu_build"]["seconds"] > 0
-    # the builder's Q carries its frames: factored form checked on every block, the chain agrees with the block chain
+    # the default route of the same blocks: frames recovered across the device, the chain agrees with the block chain;
+    # the builder's Q carries its frames and needs the check only
     fc = c3["factored"]
-    assert fc is not None and fc["factor_err_rel"] <= 1e-6 and fc["max_rel_diff_vs_block_chain"] <= 1e-5 and fc["fwd_ms"] > 0
+    assert fc["route"].startswith("factored form recovered") and fc["factor_err_rel"] <= 1e-6
+    assert fc["max_rel_diff_vs_block_chain"] <= 1e-5 and fc["fwd_ms"] > 0 and fc["recover_s"] > 0
+    assert c3["gpu_build"]["frames_hint"]["factored_form_from_the_builders_frames"] is True
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k

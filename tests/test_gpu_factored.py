@@ -213,9 +213,11 @@ def test_builder_frames_hint_serves_clouds_of_any_size(monkeypatch):
     the recovery kernel does not apply.  The chain on such a Q takes the factored form by itself and stays within 1e-5
     of the C oracle on the BLOCKS; frames that do not belong to the blocks are refused."""
     from esc_gnn_amd import get_Batch_Wjxs, get_Batch_Wjxs_both, BothTracksOperator, ScatterOperator, FactoredVectorOperator, synthetic, plan_chain
+    from esc_gnn_amd import operators
     from esc_gnn_amd.pyg_utilities import vector_route
     from esc_gnn_amd.process_pyg_data import build_PQ_batch
     from oracle import chain_oracle as co
+    monkeypatch.setattr(operators, "LARGE_RECOVERY", False)     # (the recovery of a relabelled cloud's frames has its own test: test_gpu_recover.py)
     kern = {"kernel": "gaussian", "gaussian_eps": 0.05}
     plan = plan_chain(J=4)
     ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
@@ -239,7 +241,7 @@ def test_builder_frames_hint_serves_clouds_of_any_size(monkeypatch):
         refg = co.c_chain_bsr3_bwd(rp, col, blk, G.cpu().numpy(), ev, plan.T)
         assert np.abs(W.detach().cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
         assert np.abs(xa.grad.cpu().numpy() - refg).max() <= 1e-5 * np.abs(refg).max()
-        # the same blocks without the hint: no factored form at this size (the recovery works per part of <= 512 rows)
+        # the same blocks without the hint (and without the whole-device recovery): no factored form at this size
         Q0 = ScatterOperator.from_bsr3(b["rowptr"], b["col"], b["blk"], n, validate=False)
         assert Q0.factored() is None and vector_route(Q0, x, plan.F, plan.events) is Q0
         assert _rel(get_Batch_Wjxs(x, Q0, J=4), W) <= 1e-5

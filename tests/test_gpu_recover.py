@@ -190,3 +190,60 @@ def test_recovered_form_against_the_bsr3_chain_and_the_oracle(oracle_lib, monkey
         Sf = scatter(track="vector", x0=pos, P_or_Q=op_f, kwargs=dict(diffusion_kwargs=kw))
         Sb = scatter(track="vector", x0=pos, P_or_Q=op_b, kwargs=dict(diffusion_kwargs=kw))
     _close(Sf.reshape(-1, Sf.shape[-1]), Sb.cpu().numpy().reshape(-1, Sb.shape[-1]), rtol=2e-5)   # products of two bands: 2 x 1e-5
+
+
+def test_frames_of_one_large_cloud_recovered_from_the_blocks(monkeypatch):
+    """BASELINE cfg3's shape: ONE connected cloud, far beyond a workgroup's part, blocks only (what the reference hands
+    over).  esc_gnn_amd.recover_large finds the frames across the whole device (breadth-first tree by pointer doubling,
+    gauge from the holonomies, level walk + one sweep); every block is then checked, and the chain takes the factored
+    multi-launch path by itself -- within 1e-5 of the C oracle on the BLOCKS, forward and gradient.  Random frames (every
+    second sign negative) and the builder's local-PCA frames (two columns flip together almost everywhere: the case that
+    needs the joint-diagonalisation steps).  fp16-rounded and 'procrustes' blocks are refused and stay BSR-3."""
+    from esc_gnn_amd import get_Batch_Wjxs, ScatterOperator, FactoredVectorOperator, synthetic, plan_chain, operators
+    from esc_gnn_amd.pyg_utilities import vector_route
+    from esc_gnn_amd.process_pyg_data import build_PQ_batch
+    dev = _dev()
+    monkeypatch.setenv("ESCAT_REORDER", "1")                    # relabel at this size too (the default does it from 16 384 rows on)
+    n, k = 30000, 10
+    c = synthetic.single_cloud(n, k, workers=1)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    none = (torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
+    plan = plan_chain(J=4)
+    ev = np.asarray(plan.events, dtype=np.int32).reshape(-1, 4)
+    kern = {"kernel": "gaussian", "gaussian_eps": 0.05}
+    bb = build_PQ_batch(t(c["pos"]), torch.tensor([0, n], dtype=torch.int32), k, kern)
+    cases = {"random_frames": (t(c["rowptr"]), t(c["col"]), t(c["blk"])), "local_pca_frames": (bb["rowptr"], bb["col"], bb["blk"])}
+    g = torch.Generator(device=dev).manual_seed(3)
+    for name, (rp, col, blk) in cases.items():
+        Q = ScatterOperator.from_bsr3(rp, col, blk, n, parts=none)
+        assert Q.row_perm is not None and Q._frames_hint is None
+        f = Q.factored()
+        assert isinstance(f, FactoredVectorOperator), (name, Q.factor_err)
+        assert Q.factor_err <= 1e-6 and not f.fits_register_path(plan.F)
+        x = torch.randn(3 * n, 1, device=dev, generator=g)
+        assert vector_route(Q, x, plan.F, plan.events) is f
+        xa = x.clone().requires_grad_(True)
+        W = get_Batch_Wjxs(xa, Q, J=4)
+        G = torch.randn(W.shape, device=dev, generator=g)
+        W.backward(G)
+        a = [z.cpu().numpy() for z in (rp, col, blk)]
+        ref = co.c_chain_bsr3(a[0], a[1], a[2], x.cpu().numpy().reshape(-1), ev, plan.T, plan.F)
+        refg = co.c_chain_bsr3_bwd(a[0], a[1], a[2], G.cpu().numpy(), ev, plan.T)
+        assert np.abs(W.detach().cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), name
+        assert np.abs(xa.grad.cpu().numpy() - refg).max() <= 1e-5 * np.abs(refg).max(), name
+    # refused: values rounded to fp16 (probe bypassed: the check of every block has to catch it), procrustes alignment
+    rp, col, blk = cases["random_frames"]
+    Qh = ScatterOperator.from_bsr3(rp, col, blk.half().float(), n, parts=none)
+    assert Qh.factored() is None                                                    # (the fp16 probe)
+    Qh2 = ScatterOperator.from_bsr3(rp, col, blk.half().float(), n, parts=none)
+    Qh2._fp16_probe = False
+    assert Qh2.factored() is None and Qh2.factor_err > 1e-5
+    bp = build_PQ_batch(t(c["pos"]), torch.tensor([0, n], dtype=torch.int32), k, kern, sing_vect_align_method="procrustes")
+    Qp = ScatterOperator.from_bsr3(bp["rowptr"], bp["col"], bp["blk"], n, parts=none)
+    assert Qp.factored() is None
+    x = torch.randn(3 * n, 1, device=dev, generator=g)
+    assert vector_route(Qp, x, plan.F, plan.events) is Qp
+    # switched off: the blocks stay blocks
+    monkeypatch.setattr(operators, "LARGE_RECOVERY", False)
+    Q0 = ScatterOperator.from_bsr3(rp, col, blk, n, parts=none)
+    assert Q0.factored() is None
