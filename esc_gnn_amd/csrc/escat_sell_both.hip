@@ -11,10 +11,11 @@
 // streamed once (|p| + the slot's LDS row with three sign bits = 6 B per nonzero for both tracks).
 // What made the fusion lose on paper before ("both tracks in one launch -- priced, not built") was LDS: two
 // tracks' vectors AND a six-channel output slab need 152 KB = one workgroup per CU.  This kernel has NO slab: the owner
-// of a row keeps the one open band of each track in registers (6 floats) and writes every finished band straight to its
-// place in OUT (forward), and reads the upstream gradient of a step's events straight from G one gather phase ahead
-// (backward).  LDS is the four vectors (two tracks x ping-pong, two copies each) + the staged x: 80 KB, two workgroups
-// per CU as before.
+// of a row keeps the one open band of each track in registers (6 floats); a finished band leaves through a small
+// row-ordered stage in LDS (rows * 3 floats per track: the staged x of the part until the prologue has read it), written
+// out by all threads in row order after the step's barrier (forward); the upstream gradient of a step's events is fetched
+// in row order one step ahead, under that step's gathers, and parked in the same stage for the owners (backward).
+// LDS is the four vectors (two tracks x ping-pong, two copies each) + the stage: 80 KB, two workgroups per CU as before.
 //
 // Registers per slot: v = +-|p| (sign = the vector track's channel 0; the scalar track multiplies by |v|, a free source
 // modifier) and u = 16 * LDS row | relative signs of channels 1, 2 as the top bits of bytes 2 and 3, which one SDWA
@@ -48,8 +49,8 @@ __device__ __forceinline__ void fma_one(float &a, float v, float x) { asm("v_fma
 #ifndef ESCAT_BOTH_RING
 #define ESCAT_BOTH_RING 3
 #endif
-#ifndef ESCAT_BOTH_EXP     // timing experiments only (results wrong): 1 no sign flips, 2 no vector-track gathers / FMAs,
-#define ESCAT_BOTH_EXP 0   // 4 no global event traffic, 8 no scalar-track FMAs, 16 no band write-out at all
+#ifndef ESCAT_BOTH_EXP     // timing experiments only (results wrong; `make both_exp EXP=<bits>`): 1 no sign flips, 2 no vector-track
+#define ESCAT_BOTH_EXP 0   // gathers / FMAs, 4 no global band stores, 8 no scalar-track FMAs, 16 no band write-out at all
 #endif
 
 template <int DMAX, int VSTRIDE> struct OpBoth {
@@ -309,12 +310,13 @@ k_chain_both(const int *__restrict__ colw, const float *__restrict__ mag, SellDe
         int pending = -1;                         // slot whose band waits in the stage (uniform)
         int waiting = -1;                         // slot of a second band finished at the same step: in the owners' registers
         float wP[3] = {0.f, 0.f, 0.f}, wQ[3] = {0.f, 0.f, 0.f};                 // until the stage is free (rare: last band + low-pass)
-        // The writers are the waves of the part's SHORT slices (upper half of the workgroup: rows are sorted by length), between
-        // their gathers and the step's barrier, where they would wait for the long slices anyway; a wave-store costs the CU
-        // 30-100 cycles of its one vector-memory path, which at the top of a step delayed everybody's gathers (measured).
+        // Every thread is a writer, at the top of the step after the one that parked the band.  (Measured and dropped, kept as
+        // compile-time knobs of the ablation builds: only the waves of the part's short slices write, between their gathers
+        // and the barrier where they wait for the long slices anyway -- ESCAT_BOTH_WRITERS = 2, ESCAT_BOTH_FLUSH_TOP = 0:
+        // 0.48 vs 0.38 ms per launch at cfg2.)
         // The vector track's band is parked in the local frames; the writer of element i = (row, channel c) forms row c of
         // O_row x band (frame_to_global's arithmetic).
-        #ifndef ESCAT_BOTH_WRITERS
+#ifndef ESCAT_BOTH_WRITERS
 #define ESCAT_BOTH_WRITERS 1              // 1: every wave writes; 2: the upper half of the waves
 #endif
 #ifndef ESCAT_BOTH_FLUSH_TOP
