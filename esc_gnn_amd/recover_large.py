@@ -9,7 +9,8 @@ operations in fp64 (ingest-time work, once per operator; no HIP kernel of its ow
   G_i^T R_ij G_j = diag(+-1) on every edge.
 
   1. tree: the operator was relabelled breadth-first at ingest (operators.locality_order), so the smallest neighbour
-     index of a row is its breadth-first parent and the levels are contiguous row ranges; G_i = R_i,parent G_parent down the
+     index of a row is its breadth-first parent and the levels are contiguous row ranges (several components: the same
+     levels of all of them side by side, as index lists); G_i = R_i,parent G_parent down the
      tree by POINTER DOUBLING (log2(depth) rounds of batched 3x3 products instead of ~600 dependent levels);
   2. gauge: in the tree gauge every edge's holonomy H_e = G_i^T R_ij G_j is V diag(+-1) V^T for one orthonormal V per
      component: V = eigenvectors of a pseudo-randomly weighted sum of the symmetrised H_e, then Newton steps of the joint
@@ -50,8 +51,9 @@ def workspace_bytes(nnz: int, n: int) -> int:
 
 def recover_frames_large(rowptr: torch.Tensor, col: torch.Tensor, blk: torch.Tensor, newton_steps: int = 3):
     """rowptr / col / blk (nnz, 3, 3): a BSR-3 operator whose rows are in breadth-first order.  Returns frames (n, 3, 3)
-    fp32 in that row order, or None when the row order is not breadth-first (levels not contiguous) or a block is
-    degenerate.  The frames are a CANDIDATE: the caller verifies them against every block."""
+    fp32 in that row order, or None when a block is degenerate.  The frames are a CANDIDATE: the caller verifies them
+    against every block (a row order that is not breadth-first gives a forest that does not span its components, and
+    frames that fail that check)."""
     dev = blk.device
     n = rowptr.numel() - 1
     rp, cl = rowptr.long(), col.long()
@@ -80,9 +82,7 @@ def recover_frames_large(rowptr: torch.Tensor, col: torch.Tensor, blk: torch.Ten
             break
         ptr = nxt
     root = ptr
-    lv_sorted, lv_order = torch.sort(depth, stable=True)
-    if not bool((lv_order == idx).all()):
-        return None                                             # rows are not level-ordered: not a breadth-first labelling
+    lv_sorted, lv_order = torch.sort(depth, stable=True)        # rows by level (several components: their levels side by side)
     order = torch.argsort(root, stable=True)                    # rows grouped by component
     rid, cnt = torch.unique_consecutive(root[order], return_counts=True)
     comp_of_row = torch.empty(n, dtype=torch.int64, device=dev)
@@ -117,15 +117,24 @@ def recover_frames_large(rowptr: torch.Tensor, col: torch.Tensor, blk: torch.Ten
     # 3. signs, level walk, one sweep
     sg = torch.sign((G[rows] * (B @ G[cl])).sum(dim=1))
     nlev = int(lv_sorted[-1]) + 1
-    bounds_t = torch.searchsorted(lv_sorted, torch.arange(nlev + 1, device=dev))
-    bounds, ebounds = bounds_t.tolist(), rp[bounds_t].tolist()
+    bounds = torch.searchsorted(lv_sorted, torch.arange(nlev + 1, device=dev)).tolist()
+    contiguous = bool((lv_order == idx).all())                  # one component in breadth-first order: levels are row ranges
+    ebounds = rp[torch.tensor(bounds, device=dev)].tolist() if contiguous else None
     for l in range(1, nlev):
         a, b_ = bounds[l], bounds[l + 1]
-        e0, e1 = ebounds[l], ebounds[l + 1]
-        cj = cl[e0:e1]
+        if contiguous:
+            rows_l, cnt_l = slice(a, b_), deg[a:b_]
+            ent = slice(ebounds[l], ebounds[l + 1])
+        else:
+            rows_l = lv_order[a:b_]
+            cnt_l = deg[rows_l]
+            first = torch.cumsum(cnt_l, 0) - cnt_l
+            owner = torch.repeat_interleave(torch.arange(b_ - a, device=dev), cnt_l)
+            ent = rp[rows_l][owner] + (torch.arange(owner.numel(), device=dev) - first[owner])
+        cj = cl[ent]
         use = (depth[cj] < l).double()
-        acc = torch.segment_reduce((B[e0:e1] @ G[cj]) * sg[e0:e1, None, :] * use[:, None, None], "sum", lengths=deg[a:b_], axis=0)
-        G[a:b_] = _polar(acc)
+        acc = torch.segment_reduce((B[ent] @ G[cj]) * sg[ent][:, None, :] * use[:, None, None], "sum", lengths=cnt_l, axis=0)
+        G[rows_l] = _polar(acc)
     G = _polar(torch.segment_reduce((B @ G[cl]) * sg[:, None, :], "sum", lengths=deg, axis=0))
     if not bool(torch.isfinite(G).all()):
         return None

@@ -231,8 +231,19 @@ def test_frames_of_one_large_cloud_recovered_from_the_blocks(monkeypatch):
         refg = co.c_chain_bsr3_bwd(a[0], a[1], a[2], G.cpu().numpy(), ev, plan.T)
         assert np.abs(W.detach().cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), name
         assert np.abs(xa.grad.cpu().numpy() - refg).max() <= 1e-5 * np.abs(refg).max(), name
-    # refused: values rounded to fp16 (probe bypassed: the check of every block has to catch it), procrustes alignment
+    # two clouds in one operator (two components, relabelled one after the other: the levels are no longer row ranges)
     rp, col, blk = cases["random_frames"]
+    rp2 = torch.cat([rp, rp[1:] + rp[-1]]).to(torch.int32)
+    col2 = torch.cat([col, col + n]).to(torch.int32)
+    blk2 = torch.cat([blk, blk.flip(0)[torch.argsort(torch.arange(blk.shape[0], device=dev).flip(0))]])     # (the same blocks twice)
+    Q2 = ScatterOperator.from_bsr3(rp2, col2, blk2, 2 * n, parts=none)
+    f2 = Q2.factored()
+    assert Q2.row_perm is not None and isinstance(f2, FactoredVectorOperator) and Q2.factor_err <= 1e-6
+    x2 = torch.randn(6 * n, 1, device=dev, generator=g)
+    W2 = get_Batch_Wjxs(x2, Q2, J=4)
+    W1 = get_Batch_Wjxs(x2[: 3 * n].contiguous(), ScatterOperator.from_bsr3(rp, col, blk, n, parts=none), J=4)
+    assert float((W2[: 3 * n] - W1).abs().max() / W1.abs().max()) <= 1e-5
+    # refused: values rounded to fp16 (probe bypassed: the check of every block has to catch it), procrustes alignment
     Qh = ScatterOperator.from_bsr3(rp, col, blk.half().float(), n, parts=none)
     assert Qh.factored() is None                                                    # (the fp16 probe)
     Qh2 = ScatterOperator.from_bsr3(rp, col, blk.half().float(), n, parts=none)
