@@ -110,7 +110,7 @@ def recover_frames_large(rowptr: torch.Tensor, col: torch.Tensor, blk: torch.Ten
         Th[:, 0, 1], Th[:, 0, 2], Th[:, 1, 2] = th[:, 0], th[:, 1], th[:, 2]
         V = V @ torch.linalg.matrix_exp(Th - Th.transpose(1, 2))
         del Ve, Hp
-        if float(th.abs().max()) < 1e-9:
+        if float(th.abs().max()) < 1e-6:          # (quadratic: what is left after this correction is its square)
             break
     del H
     G = G @ V[comp_of_row]
