@@ -339,3 +339,41 @@ def test_operator_cache_follows_in_place_edits():
         assert float(op2.csr().val.sum()) == 4.0
     finally:
         operators.ScatterOperator.from_torch = orig
+
+
+def test_frames_of_a_relabelled_cloud_recovered_from_its_blocks_on_the_host():
+    """esc_gnn_amd/recover_large.py is batched torch: the same code runs here on CPU tensors.  One cloud, blocks built from
+    random orthonormal frames, rows relabelled breadth-first (operators.locality_order): the recovered frames reproduce
+    every block as p_ij G_i diag(+-1) G_j^T to 1e-6 of max|Q| (they differ from the true frames by a column permutation
+    and signs, which is the operator's own gauge freedom)."""
+    import torch
+    from esc_gnn_amd import synthetic
+    from esc_gnn_amd.operators import locality_order
+    from esc_gnn_amd.recover_large import recover_frames_large
+    c = synthetic.single_cloud(1500, 8, workers=1)
+    n = c["N"]
+    rowptr, col, blk = torch.from_numpy(c["rowptr"]), torch.from_numpy(c["col"]), torch.from_numpy(c["blk"])
+    perm = locality_order(rowptr, col, n)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(n)
+    rp = rowptr.long()
+    rows_old = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+    r2, c2 = inv[rows_old], inv[col.long()]
+    order = torch.argsort(r2 * n + c2)
+    rows_new, col_new, blk_new = r2[order], c2[order], blk[order]
+    rowptr_new = torch.zeros(n + 1, dtype=torch.int64); rowptr_new[1:] = torch.cumsum(torch.bincount(rows_new, minlength=n), 0)
+    G = recover_frames_large(rowptr_new.to(torch.int32), col_new.to(torch.int32), blk_new)
+    assert G is not None and G.shape == (n, 3, 3)
+    assert (torch.einsum("nac,nbc->nab", G, G) - torch.eye(3)).abs().max() < 1e-6                     # orthonormal
+    M = G.double()[rows_new].transpose(1, 2) @ blk_new.double() @ G.double()[col_new]
+    d = torch.diagonal(M, dim1=1, dim2=2)
+    p = blk_new.double()[:, 0, :].norm(dim=1)
+    off = (M - torch.diag_embed(torch.where(d >= 0, p[:, None], -p[:, None]))).abs().max()
+    assert float(off / blk_new.abs().max()) <= 1e-6
+    # not such an operator (every block rotated at random): frames come back, but they do not reproduce the blocks
+    g = torch.Generator().manual_seed(0)
+    Rn = torch.linalg.qr(torch.randn(blk_new.shape[0], 3, 3, generator=g))[0]
+    Gb = recover_frames_large(rowptr_new.to(torch.int32), col_new.to(torch.int32), (blk_new @ Rn).contiguous())
+    if Gb is not None:
+        Mb = Gb.double()[rows_new].transpose(1, 2) @ (blk_new @ Rn).double() @ Gb.double()[col_new]
+        db = torch.diagonal(Mb, dim1=1, dim2=2)
+        assert float((Mb - torch.diag_embed(db)).abs().max() / blk_new.abs().max()) > 1e-3
