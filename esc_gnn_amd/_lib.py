@@ -95,7 +95,15 @@ _lib = None
 
 
 class EscatError(RuntimeError):
-    pass
+    """a library call failed; `code` is its return value (include/escat.h: ESCAT_EINVAL -1, ESCAT_ERANGE -2, ...), None when
+    the failure is on the Python side"""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
+
+
+ESCAT_ERANGE = -2
 
 
 def load():
@@ -119,4 +127,4 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().escat_last_error()
-        raise EscatError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+        raise EscatError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}", code=int(rc))

@@ -181,7 +181,7 @@ def bank_both(x_s, P_op, x_v, Q_op, plan):
     try:
         Ws, Wv = _BothBank.apply(x_s, x_v.view(-1, 3), bop, plan, view)
     except _lib.EscatError as e:         # an event table the fused kernel does not serve (ESCAT_ERANGE)
-        if "code -2" in str(e):
+        if e.code == _lib.ESCAT_ERANGE:
             return None
         raise
     return Ws, Wv.view(x_v.shape[0], 1, plan.F)
