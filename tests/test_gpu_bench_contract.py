@@ -32,6 +32,7 @@ def test_bench_json_contract():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert rf["frac"] <= 1.0 and "lds" in rf and rf["lds"]["frac"] <= 1.0 and "algorithmic_GBs" in rf
+    assert d["steady_state"]["steps"] == 200 and d["steady_state"]["ms_per_step"] > 0 and d["steady_state"]["unit"] == "graphs/s"
     c3 = d["cfg3"]
     assert c3["nodes"] == 30000 and c3["fwd_ms"] > 0 and c3["roofline"]["bound"] == "hbm" and c3["telescoping_max_abs_err"] < 1e-4
     assert c3["gpu_build"]["pattern_equal_to_host_kdtree"] is True and c3["gpu_build"]["seconds"] > 0
