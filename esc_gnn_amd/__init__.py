@@ -18,5 +18,6 @@ from .scales import ChainPlan, plan_chain                     # noqa: F401
 from .pyg_utilities import get_Batch_Wjxs                     # noqa: F401
 from .scatter import scatter, scatter_both, escat_scatter, ScatteringCache     # noqa: F401
 from .both import get_Batch_Wjxs_both, BothTracksOperator     # noqa: F401
+from .store import load_operator_store, ScatteringStore       # noqa: F401
 from .invariants import get_vector_invariants                 # noqa: F401
 from .infogain import calc_infogain_wavelet_scales            # noqa: F401

@@ -171,7 +171,14 @@ def scatter_both(*, x0_scalar, P, x0_vector, Q, kwargs, ablate_second_order_wave
 
 def escat_scatter(self, *, track, x0, P_or_Q, kwargs):
     """method form: assign to ESCGNNModular._scatter (reads self.ablate_second_order_wavelets).  If the model carries
-    an `escat_cache` attribute (a ScatteringCache) repeated calls on the same batch reuse the coefficients."""
+    an `escat_cache` attribute (a ScatteringCache) repeated calls on the same batch reuse the coefficients; with an
+    `escat_store` (esc_gnn_amd.store.ScatteringStore, the whole dataset's coefficients) and an active batch
+    (store.set_batch(sample_ids)) gradient-free calls are answered from the store."""
+    store = getattr(self, 'escat_store', None)
+    if store is not None and not (torch.is_grad_enabled() and x0.requires_grad):
+        W = store.lookup(track, x0)
+        if W is not None:
+            return W
     return scatter(track=track, x0=x0, P_or_Q=P_or_Q, kwargs=kwargs,
                    ablate_second_order_wavelets=bool(getattr(self, 'ablate_second_order_wavelets', False)),
                    cache=getattr(self, 'escat_cache', None))
