@@ -159,7 +159,7 @@ def bank_both(x_s, P_op, x_v, Q_op, plan):
         # mini-batches drawn from a stored operator (ScatterOperator.select / FactoredVectorOperator.select): the stored P
         # and Q pair once, the batch is the same list of parts of the fused operator
         Qv = Q_op.signed if isinstance(Q_op, FactoredVectorOperator) else Q_op
-        if not isinstance(Qv, OperatorBatch) or not (P_op.part_ids is Qv.part_ids or bool(torch.equal(P_op.part_ids, Qv.part_ids))):
+        if not isinstance(Qv, OperatorBatch) or not P_op.same_parts(Qv):
             return None
         Qb = Qv.base
         if isinstance(Q_op, FactoredVectorOperator):
@@ -171,7 +171,7 @@ def bank_both(x_s, P_op, x_v, Q_op, plan):
             return None
         view = getattr(P_op, "_both_view", None)
         if view is None or view.base is not bop.fop.signed:
-            view = P_op._both_view = bop.fop.signed.select(P_op.part_ids)
+            view = P_op._both_view = bop.fop.signed.select(P_op)
         if view.n != x_s.shape[0]:
             return None
     else:

@@ -504,7 +504,7 @@ class SellGlobal:
 
 class _Csr:
     __slots__ = ("rowptr", "col", "val", "n", "nnz", "part_ptr", "n_parts", "max_part_rows", "_max_row_nnz", "_sell", "_sell_g",
-                 "_signed", "policy", "fp16_probe")
+                 "_signed", "policy", "fp16_probe", "_pp_host")
 
     def __init__(self, rowptr, col, val, n, parts=None):
         self.rowptr, self.col, self.val, self.n = rowptr, col, val, n
@@ -518,6 +518,12 @@ class _Csr:
         self._signed = None
         self.policy = None              # None: the module's INGEST_POLICY; set by the owning ScatterOperator
         self.fp16_probe = None          # _fp16_probe(val), when somebody has asked already
+        self._pp_host = None            # part_ptr_host(): numpy copy for the host-side bookkeeping of mini-batch views
+
+    def part_ptr_host(self) -> np.ndarray:
+        if self._pp_host is None:
+            self._pp_host = self.part_ptr.detach().cpu().numpy().astype(np.int64)
+        return self._pp_host
 
     @property
     def max_row_nnz(self) -> int:
@@ -1075,17 +1081,29 @@ class OperatorBatch:
             raise ValueError("escat: a locality-relabelled operator (one large connected block) cannot be batched by parts")
         self.base = base
         self.device = base.device
-        ids = torch.as_tensor(part_ids, device=base.device).to(torch.int64).flatten()
         form = base.bsr3() if base.has_bsr3 else base.csr()
-        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= form.n_parts):
+        # the bookkeeping of a view is done on the host (a numpy copy of the part ranges, made once per stored operator): a
+        # 32-sample batch costs one small copy instead of a chain of device reductions with a host round trip each
+        if isinstance(part_ids, OperatorBatch):         # the same parts of another stored operator: share the lists
+            ids_h, ids = part_ids._ids_host, part_ids.part_ids
+        elif torch.is_tensor(part_ids):
+            ids_h = part_ids.detach().to("cpu", torch.int64).numpy().reshape(-1)
+            ids = part_ids.detach().to(device=base.device, dtype=torch.int64).flatten()
+        else:
+            ids_h = np.asarray(part_ids, dtype=np.int64).reshape(-1)
+            ids = torch.from_numpy(ids_h).to(base.device)
+        if ids_h.size and (int(ids_h.min()) < 0 or int(ids_h.max()) >= form.n_parts):
             raise IndexError("escat: part id outside the stored operator")
         self.part_ids = ids
+        self._ids_host = ids_h
         self._ref_parts = form.n_parts
-        pp = form.part_ptr.long()
-        rows = (pp[1:] - pp[:-1])[ids]
+        pp = form.part_ptr_host()
         self._unit = 3 if base.has_bsr3 else 1          # scalar rows per row of the reference form
-        self.n = int(rows.sum()) * self._unit
+        self.n = int((pp[1:] - pp[:-1])[ids_h].sum()) * self._unit
         self._lists = {}
+
+    def same_parts(self, other: "OperatorBatch") -> bool:
+        return self.part_ids is other.part_ids or np.array_equal(self._ids_host, other._ids_host)
 
     def lists_for(self, form):
         """(part_list, part_row0) int32 device tensors in the row units of `form`."""
@@ -1094,24 +1112,39 @@ class OperatorBatch:
             if form.n_parts != self._ref_parts:
                 raise RuntimeError("escat: this form of the stored operator is partitioned differently; build the store "
                                    "with explicit parts (one per sample)")
-            pp = form.part_ptr.long()
-            rows = (pp[1:] - pp[:-1])[self.part_ids]
-            row0 = _cumsum0(rows)[:-1]
-            self._lists[key] = (self.part_ids.to(torch.int32).contiguous(), row0.to(torch.int32).contiguous())
+            pp = form.part_ptr_host()
+            rows = (pp[1:] - pp[:-1])[self._ids_host]
+            row0 = np.cumsum(rows) - rows
+            both = torch.from_numpy(np.stack([self._ids_host, row0]).astype(np.int32)).to(self.device)
+            self._lists[key] = (both[0], both[1])
         return self._lists[key]
 
     def row_index(self) -> torch.Tensor:
         """scalar rows of the stored operator, in batch order (to gather x / targets kept per dataset)."""
         base = self.base
         form = base.bsr3() if base.has_bsr3 else base.csr()
-        pp = form.part_ptr.long()
-        start, rows = pp[:-1][self.part_ids], (pp[1:] - pp[:-1])[self.part_ids]
-        off = _cumsum0(rows)
-        idx = torch.arange(int(off[-1]), device=self.device) - torch.repeat_interleave(off[:-1], rows) \
-            + torch.repeat_interleave(start, rows)
-        if self._unit == 3:
-            idx = (3 * idx[:, None] + torch.arange(3, device=self.device)[None, :]).reshape(-1)
-        return idx
+        return rows_of_ranges(form.part_ptr_host(), self._ids_host, self.device, self._unit,
+                              form.part_ptr if self.part_ids.is_cuda else None, self.part_ids)
+
+
+def rows_of_ranges(ptr_host: np.ndarray, ids_host: np.ndarray, device, unit: int = 1, ptr_dev=None, ids_dev=None) -> torch.Tensor:
+    """concatenation of the index ranges [ptr[i], ptr[i+1]) for i in ids (each index expanded to `unit` consecutive ones):
+    built on the host and uploaded when short, on the device (sizes known from the host: no round trip) when long"""
+    lens = (ptr_host[1:] - ptr_host[:-1])[ids_host]
+    total = int(lens.sum())
+    if total <= (1 << 17) or ptr_dev is None:
+        off = np.cumsum(lens) - lens
+        idx = np.arange(total, dtype=np.int64) + np.repeat(ptr_host[:-1][ids_host] - off, lens)
+        if unit != 1:
+            idx = (unit * idx[:, None] + np.arange(unit, dtype=np.int64)[None, :]).reshape(-1)
+        return torch.from_numpy(idx).to(device)
+    pp = ptr_dev.long()
+    start, rows = pp[:-1][ids_dev], (pp[1:] - pp[:-1])[ids_dev]
+    off = torch.cumsum(rows, 0) - rows
+    idx = torch.arange(total, device=device) + torch.repeat_interleave(start - off, rows, output_size=total)
+    if unit != 1:
+        idx = (unit * idx[:, None] + torch.arange(unit, device=device)[None, :]).reshape(-1)
+    return idx
 
 
 def _validate(rowptr, col, n):

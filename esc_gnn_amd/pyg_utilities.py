@@ -248,7 +248,7 @@ def vector_route(op, x, F: int, events=()):
         f = op.base.factored()
         if f is not None and f.fits_register_path(F):
             if getattr(op, "_factored_view", None) is None:
-                op._factored_view = f.select(op.part_ids)      # the same parts of the signed operator, the frames whole
+                op._factored_view = f.select(op)               # the same parts of the signed operator, the frames whole
             return op._factored_view
     return op
 

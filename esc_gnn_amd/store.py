@@ -106,6 +106,7 @@ class ScatteringStore:
         if x_scalar.shape[0] != int(gp[-1]) or x_vector.shape[0] != int(gp[-1]) or x_vector.shape[1] != 3:
             raise ValueError("escat: x_scalar (N, C) and x_vector (N, 3) must cover the store's nodes")
         self.graph_ptr = gp
+        self._gp_host = gp.cpu().numpy()
         self.n_samples = B
         self.kwargs = kwargs
         self.ablate = bool(ablate_second_order_wavelets)
@@ -116,10 +117,11 @@ class ScatteringStore:
         with torch.no_grad():
             for g0 in range(0, B, chunk_graphs):
                 g1 = min(B, g0 + chunk_graphs)
-                ids = torch.arange(g0, g1, device=P.device)
+                ids = np.arange(g0, g1)
                 r0, r1 = int(gp[g0]), int(gp[g1])
-                ws, wv = scatter_both(x0_scalar=xs[r0:r1].contiguous(), P=P.select(ids), x0_vector=xv[r0:r1].contiguous(),
-                                      Q=Q.select(ids), kwargs=kwargs, ablate_second_order_wavelets=self.ablate)
+                Pv = P.select(ids)
+                ws, wv = scatter_both(x0_scalar=xs[r0:r1].contiguous(), P=Pv, x0_vector=xv[r0:r1].contiguous(),
+                                      Q=Q.select(Pv), kwargs=kwargs, ablate_second_order_wavelets=self.ablate)
                 if self.Ws is None:
                     self.Ws = torch.empty((int(gp[-1]),) + tuple(ws.shape[1:]), dtype=torch.float32, device=P.device)
                     self.Wv = torch.empty((int(gp[-1]),) + tuple(wv.shape[1:]), dtype=torch.float32, device=P.device)
@@ -128,14 +130,19 @@ class ScatteringStore:
 
     def rows_of(self, sample_ids) -> torch.Tensor:
         """node rows of the samples, in batch order (what PyG's collate concatenates)"""
+        from .operators import rows_of_ranges
         gp = self.graph_ptr
-        ids = torch.as_tensor(sample_ids, device=gp.device).to(torch.int64).flatten()
-        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.n_samples):
+        if torch.is_tensor(sample_ids):
+            ids_h = sample_ids.detach().to("cpu", torch.int64).numpy().reshape(-1)
+            ids_d = sample_ids.detach().to(device=gp.device, dtype=torch.int64).flatten()
+        else:
+            ids_h = np.asarray(sample_ids, dtype=np.int64).reshape(-1)
+            ids_d = None
+        if ids_h.size and (int(ids_h.min()) < 0 or int(ids_h.max()) >= self.n_samples):
             raise IndexError("escat: sample id outside the store")
-        start, lens = gp[:-1][ids], (gp[1:] - gp[:-1])[ids]
-        off = torch.cumsum(lens, 0) - lens
-        total = int(lens.sum())
-        return torch.arange(total, device=gp.device) - torch.repeat_interleave(off, lens) + torch.repeat_interleave(start, lens)
+        if ids_d is None and int((self._gp_host[1:] - self._gp_host[:-1])[ids_h].sum()) > (1 << 17):
+            ids_d = torch.from_numpy(ids_h).to(gp.device)
+        return rows_of_ranges(self._gp_host, ids_h, gp.device, 1, gp if ids_d is not None else None, ids_d)
 
     def batch(self, sample_ids):
         """(scatter(track='scalar') (n, C, W), scatter(track='vector') (n, 1, 3, W)) of the batch made of these samples"""
