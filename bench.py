@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--J", type=int, default=4)
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the settled-device measurement (260 more steps: profiling runs)")
     ap.add_argument("--no-fresh-coo", action="store_true", help="skip the function-level drop-in measurement on fresh COO tensors")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the secondary cfg3 measurement (one large cloud, N = 1 only)")
     ap.add_argument("--cfg3-nodes", type=int, default=2_000_000)
@@ -559,16 +560,17 @@ def main():
             # MI355X takes ~40 of these steps (30 ms) to reach its steady clock for this kernel -- per-step times 0.74 ->
             # 0.84 -> 0.68 ms, profiles/r3c_step_time_after_idle.json, tools/host_overhead.py -- so a window of K = 20 steps
             # after W = 5 sits inside that ramp; a training loop runs in the settled state.
-            for _ in range(60):
-                main_step(False)
-            torch.cuda.synchronize(); ts0 = time.perf_counter()
-            for _ in range(200):
-                main_step(False)
-            torch.cuda.synchronize(); dts = time.perf_counter() - ts0
-            out["steady_state"] = {"value": args.graphs * 200 / dts, "unit": "graphs/s", "ms_per_step": dts / 200 * 1e3, "steps": 200,
-                                   "untimed_steps_before": 60 + args.warmup + args.steps,
-                                   "note": "the same step after the device's power management has settled on this kernel (the "
-                                           "headline window of --steps after --warmup lies inside the ~40-step ramp when both are small)"}
+            if not args.no_steady_state:
+                for _ in range(60):
+                    main_step(False)
+                torch.cuda.synchronize(); ts0 = time.perf_counter()
+                for _ in range(200):
+                    main_step(False)
+                torch.cuda.synchronize(); dts = time.perf_counter() - ts0
+                out["steady_state"] = {"value": args.graphs * 200 / dts, "unit": "graphs/s", "ms_per_step": dts / 200 * 1e3, "steps": 200,
+                                       "untimed_steps_before": 60 + args.warmup + args.steps,
+                                       "note": "the same step after the device's power management has settled on this kernel (the "
+                                               "headline window of --steps after --warmup lies inside the ~40-step ramp when both are small)"}
             # secondary, NOT the headline: the same step with the routing of the vector operator forced (same inputs)
             from esc_gnn_amd import FactoredVectorOperator, operators as _ops
             out["variants"] = {}

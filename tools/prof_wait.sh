@@ -6,7 +6,7 @@ out=$root/gpurun_out/wait_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS \
-    --output-format csv -d $out -- python3 $root/bench.py --steps 3 --warmup 1 --gen-workers 1 --no-cpu-baseline --no-cfg3 > $out/bench.json 2> $out/err.log || { tail -5 $out/err.log; exit 1; }
+    --output-format csv -d $out -- python3 $root/bench.py --steps 3 --warmup 1 --gen-workers 1 --no-cpu-baseline --no-cfg3 --no-steady-state > $out/bench.json 2> $out/err.log || { tail -5 $out/err.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections, json
 d = collections.defaultdict(lambda: collections.defaultdict(list))
