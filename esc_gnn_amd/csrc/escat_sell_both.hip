@@ -46,8 +46,8 @@ template <int B> __device__ __forceinline__ float flip_by(float x, unsigned u)
 __device__ __forceinline__ void fma_abs(float &a, float v, float x) { asm("v_fma_f32 %0, |%1|, %2, %0" : "+v"(a) : "v"(v), "v"(x)); }
 __device__ __forceinline__ void fma_one(float &a, float v, float x) { asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(a) : "v"(v), "v"(x)); }
 
-#ifndef ESCAT_BOTH_RING
-#define ESCAT_BOTH_RING 3
+#ifndef ESCAT_BOTH_RING      // slots in flight per lane.  2: as fast as 3 at 20 slots (0.344 vs 0.346 ms forward on a settled device), and
+#define ESCAT_BOTH_RING 2    // the eight registers it frees end the spills of the 24-slot instances (k = 14: 0.395 + 0.402 vs 0.404 + 0.422)
 #endif
 #ifndef ESCAT_BOTH_EXP     // timing experiments only (results wrong; `make both_exp EXP=<bits>`): 1 no sign flips, 2 no vector-track
 #define ESCAT_BOTH_EXP 0   // gathers / FMAs, 4 no global band stores, 8 no scalar-track FMAs, 16 no band write-out at all
