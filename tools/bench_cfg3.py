@@ -50,7 +50,10 @@ def main():
             tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
     tf /= args.reps; tb /= args.reps
     alg = T * (4 * (N + 1) + 40 * nnz) + 12 * N + 12 * N * F
-    out = {"workload": f"cfg3: single cloud n={N}, k={args.k}, Q BSR-3 chain J={args.J} (T={T}, F={F})", "nnz_blocks": nnz,
+    route = "factored form recovered from the blocks (multi-launch k_csr_step)" if op.factored() is not None else "blocks (k_bsr3_step_staged)"
+    out = {"workload": f"cfg3: single cloud n={N}, k={args.k}, Q given as BSR-3 blocks, chain J={args.J} (T={T}, F={F})", "route": route,
+           "note": "ESCAT_Q_FACTOR_LARGE=0 keeps the blocks; fwd_alg_GBs / frac_of_8TBs use the BLOCK chain's algorithmic bytes",
+           "nnz_blocks": nnz,
            "mean_row_blocks": nnz / N, "fwd_ms": tf, "fwd_alg_GBs": alg / (tf * 1e-3) / 1e9, "fwd_ms_per_step": tf / T,
            "frac_of_8TBs": alg / (tf * 1e-3) / 1e9 / 8000.0, "gen_s": gen_s}
     if args.bwd:
